@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""Headline benchmark: MC-dropout range-image scans/s (64x2048x5, T=8) on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic scans resident in HBM:
+  T=8 stochastic SalsaNext forwards per scan (Dropout2d live, BatchNorm frozen)  ->  fused
+  softmax / mean-over-T / predictive-entropy / mutual-information / argmax reduction  ->
+  on-device confusion-matrix and ECE-bin accumulation.
+`value` = scans of all ranks / max-over-ranks wall time.  Scans are independent, so ranks shard them
+with no data-path collective ("weak" scaling); the 20x20 confusion matrix is all-reduced once after
+the timed region, as an evaluation run would.
+
+    python bench.py [--gpus N --steps K --warmup W]          # N>1: launched by torch.distributed.run
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W, T, NCLS = 64, 2048, 8, 20
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(model_sd, x_cpu, threads):
+    """The oracle (CPU restatement, pinned against the reference) on the host cores: one MC scan
+    (T=8 passes of one 64x2048 scan with dropout multipliers + the reduction), after one warm-up pass."""
+    from oracle import salsanext as osalsa, uncertainty as ounc
+    torch.set_num_threads(threads)
+    x1 = x_cpu[:1]
+    with torch.no_grad():
+        osalsa.salsanext_forward(model_sd, x1)                       # warm-up (oneDNN primitive cache)
+        t0 = time.perf_counter()
+        outs = []
+        g = torch.Generator().manual_seed(0)
+        for _ in range(T):
+            outs.append(osalsa.salsanext_forward(model_sd, x1, osalsa.draw_dropout_scales(1, 0.2, g)))
+        ounc.mc_reduce(torch.stack(outs, 0))
+        dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "scans/s", "cores": threads, "kind": "port",
+            "sample": f"1 scan 64x2048x5, T={T} passes + MC reduction, torch-CPU oracle, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scans", type=int, default=4, help="scans per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+
+    from semanticlidarunc_amd import ops
+    from semanticlidarunc_amd.metrics.ece import ECEAggregator
+    from semanticlidarunc_amd.models.evaluator import IoUEvaluator
+    from semanticlidarunc_amd.salsanext import SalsaNext
+    from semanticlidarunc_amd.testing import seeded_model, synthetic_scan
+    from semanticlidarunc_amd.utils.mc_dropout import mc_predict
+
+    model = seeded_model(SalsaNext)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    x_cpu, labels_cpu = synthetic_scan(args.scans, H, W, seed=1234 + rank)
+    x, labels = x_cpu.to(dev), labels_cpu.to(dev)
+    iou, ece = IoUEvaluator(NCLS), ECEAggregator(n_bins=15, mode="probs", ignore_index=0, max_samples=500000)
+    torch.manual_seed(100 + rank)
+
+    def step():
+        p_bar, h_norm, mi_norm, preds = mc_predict(model, [x], T=T)
+        iou.update(preds, labels)
+        ece.update(p_bar, labels)
+        return h_norm
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    iou.reset(); ece.reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.all_reduce(iou.confmat, op=dist.ReduceOp.SUM)            # the evaluation's one exchange
+    miou, _ = iou.compute([str(i) for i in range(NCLS)], test_mask=[0] + [1] * (NCLS - 1), ignore_gt=[0])
+    (ece_v, _), _ = ece.compute()[:2]
+
+    # ---- roofline of the dominant kernel: one extra step with HIP events around every conv launch ----
+    ops.TIMING = []
+    step()
+    torch.cuda.synchronize()
+    per_kernel = {}
+    for name, flops, nbytes, e0, e1 in ops.TIMING:
+        k = per_kernel.setdefault(name, [0, 0.0, 0.0, 0.0])
+        k[0] += 1; k[1] += flops; k[2] += nbytes; k[3] += e0.elapsed_time(e1) * 1e-3
+    ops.TIMING = None
+    conv_s = sum(k[3] for k in per_kernel.values())
+    conv_flops = sum(k[1] for k in per_kernel.values())
+    dom = max(per_kernel, key=lambda n: per_kernel[n][3])
+    n_l, fl, by, sec = per_kernel[dom]
+    achieved = fl / sec / 1e12
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n_l, "avg_launch_us": round(sec / n_l * 1e6, 1),
+                "algorithmic_gflop_per_launch": round(fl / n_l / 1e9, 3),
+                "hbm_frac_same_kernel": round(by / sec / 1e9 / HBM_PEAK_GBS, 4),
+                "all_convs": {"tflops": round(conv_flops / conv_s / 1e12, 2), "ms_per_step": round(conv_s * 1e3, 2),
+                              "frac": round(conv_flops / conv_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}}
+
+    if rank == 0:
+        scans = args.scans * world * args.steps
+        out = {
+            "metric": "range-image scans/sec (64x2048, T=8 MC)", "value": round(scans / dt, 3), "unit": "scans/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SalsaNext MC-dropout T={T} + entropy/MI map + IoU/ECE accumulation, "
+                                   f"{args.scans} scans of {H}x{W}x5 per step per GPU (BASELINE configs[2] shape, fp32)",
+                       "scans_per_step_per_gpu": args.scans, "T": T, "parallelism": f"scan-sharded x{world}"},
+            "parity": {"mIoU_random_labels": round(miou, 6), "ece": round(ece_v, 6)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, x_cpu, threads=min(16, os.cpu_count() or 1))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/*
+ * slu.h -- C ABI of libslu_hip.so: the MI355X (gfx950) kernels behind the SemanticLiDARUnc
+ * range-image hot path.
+ *
+ * The reference (kav-institute/SemanticLiDARUnc) is pure Python on torch: it has no FFI layer, so
+ * there is no reference-side binding to replace one-for-one.  Each entry point below names the
+ * reference Python code whose arithmetic it replaces (path:line under the reference's src/), and
+ * INTEGRATION.md shows the ctypes stub a maintainer adds to call it.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the comment says HOST; tensors are dense NCHW fp32
+ *    (W = azimuth fastest), labels / predictions int64, exactly the layouts the reference uses;
+ *  - the library never allocates, frees or synchronises: outputs and scratch are caller-owned,
+ *    every launch is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default);
+ *  - return value 0 = launched, negative = SLU_E* (nothing was launched); never throws/exits;
+ *  - re-entrant, no mutable global state.
+ */
+#ifndef SLU_H_
+#define SLU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLU_ABI_VERSION 1
+
+#define SLU_OK            0
+#define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
+#define SLU_EUNSUPPORTED -2   /* shape or kernel family outside what the library instantiates */
+#define SLU_ELAUNCH      -3   /* hipGetLastError() != hipSuccess right after the launch       */
+
+typedef void* slu_stream_t;
+
+int slu_abi_version(void);
+const char* slu_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution (replaces nn.Conv2d + nn.LeakyReLU + eval nn.BatchNorm2d + residual add +
+ * torch.cat + nn.PixelShuffle(2) + nn.Dropout2d of  baselines/SalsaNext/SalsaNext.py:25-39,
+ * :73-109, :142-170, :213)
+ *
+ *   out[n,co,y,x] = resid[n,co,y,x]
+ *                 + bn_a[co] * leaky( bias[co] + sum_{ci,i,j} w[co,ci,i,j] * in[n,ci,y-pad+i*dil,x-pad+j*dil] ) + bn_b[co]
+ *
+ * `in` is the channel concatenation of up to 3 sources; a source may be read through
+ * PixelShuffle(2) and multiplied by a per-(n, source-channel) factor (folded Dropout2d).
+ * Stride 1, "same" output size; kernel families (ksize,dil,pad) = (1,1,0) (3,1,1) (3,2,2) (2,2,1).
+ * ------------------------------------------------------------------------------------------ */
+#define SLU_MAX_SRC 3
+
+typedef struct slu_conv_src {
+  const float* ptr;    /* [N, C, H, W]  or, when pixel_shuffle, [N, C, H/2, W/2]                */
+  const float* scale;  /* [N, C] multiplier per (sample, source channel), or NULL               */
+  int32_t C;           /* channels of the stored tensor                                          */
+  int32_t pixel_shuffle; /* 1: contributes C/4 channels, in[c,y,x] = ptr[4c+2(y&1)+(x&1), y/2, x/2] */
+} slu_conv_src;
+
+typedef struct slu_conv_desc {   /* HOST struct */
+  slu_conv_src src[SLU_MAX_SRC];
+  int32_t nsrc;
+  int32_t N, H, W;       /* output (= input) spatial size                                        */
+  int32_t Cin, Cout;     /* Cin = sum of contributed channels                                    */
+  int32_t ksize, dil, pad;
+  int32_t ck;            /* K-chunk the weights were packed with (slu_conv_ck)                   */
+  const float* wpack;    /* slu_pack_conv_weight output                                          */
+  const float* bias;     /* [Cout] or NULL                                                       */
+  int32_t has_act;       /* 1: leaky(v) = v > 0 ? v : slope * v                                  */
+  float slope;
+  const float* bn_a;     /* [Cout] or NULL (then bn_b ignored): folded eval BatchNorm            */
+  const float* bn_b;
+  const float* resid;    /* [N, Cout, H, W] or NULL                                              */
+  float* out;            /* [N, Cout, H, W]                                                      */
+} slu_conv_desc;
+
+/* K-chunk (input channels staged per LDS round) used for a kernel family. */
+int slu_conv_ck(int ksize);
+/* number of floats of the packed (MFMA A-fragment ordered, zero padded) weight image */
+size_t slu_packed_weight_floats(int cout, int cin, int ksize, int ck);
+/* w: [cout, cin, ksize, ksize] (torch OIHW) -> out: packed image.  Re-run after every weight update. */
+int slu_pack_conv_weight(const float* w, int cout, int cin, int ksize, int ck, float* out, slu_stream_t stream);
+int slu_conv2d_fwd(const slu_conv_desc* desc, slu_stream_t stream);
+/* name of the kernel instantiation slu_conv2d_fwd launches for `desc` (as rocprofv3 prints it); HOST buf >= 48 bytes */
+int slu_conv2d_kernel_name(const slu_conv_desc* desc, char* buf, size_t buflen);
+
+/* a = gamma / sqrt(var + eps), b = beta - mean * a   (eval-mode nn.BatchNorm2d, SalsaNext.py:32,36,...) */
+int slu_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                int C, float* a, float* b, slu_stream_t stream);
+
+/* nn.AvgPool2d(3, stride=2, padding=1) (count_include_pad) of x * scale[n,c]  (SalsaNext.py:69,98-101).
+ * x [N,C,H,W] -> y [N,C,(H+1)/2,(W+1)/2]; scale [N,C] or NULL. */
+int slu_avgpool3s2_fwd(const float* x, const float* scale, float* y, int N, int C, int H, int W,
+                       slu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MC-dropout reduction (replaces models/trainer.py:1105-1136,1143-1154 = tester.py:412-451)
+ *   probs_t = exp(log_softmax(logits_t)); p_bar = mean_t probs_t;
+ *   H_norm = -sum_c clamp(p_bar,eps) ln clamp(p_bar,eps) / ln C
+ *   MI_norm = max(0, (H - mean_t H[probs_t]) / ln C);  preds = argmax_c p_bar (first max wins)
+ * logits [T,B,C,HW]; p_bar [B,C,HW]; h_norm, mi_norm [B,HW]; preds int64 [B,HW].  C <= 32.
+ * ------------------------------------------------------------------------------------------ */
+int slu_mc_reduce(const float* logits, int T, int B, int C, int HW, float eps,
+                  float* p_bar, float* h_norm, float* mi_norm, int64_t* preds, slu_stream_t stream);
+
+/* Single-pass eval (replaces models/trainer.py:1180-1184,1211-1214):
+ *   probs = exp(log_softmax(logits)); preds = argmax; H_norm = -sum p ln max(p, eps) / ln C */
+int slu_softmax_entropy(const float* logits, int B, int C, int HW, float eps,
+                        float* probs, float* h_norm, int64_t* preds, slu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Metrics
+ * ------------------------------------------------------------------------------------------ */
+/* confmat[t*C+p] += 1 for every pixel with 0 <= t,p < C   (models/evaluator.py:45-53; rows = GT) */
+int slu_confusion_update(const int64_t* preds, const int64_t* targets, int64_t n, int C,
+                         int64_t* confmat, slu_stream_t stream);
+
+/* Top-label calibration bins (metrics/ece.py:55-84,136-140), mode 'probs':
+ *   p = max(probs,0) / max(sum_c, 1e-12); conf = clamp(max_c p, 0, 1); correct = argmax == label;
+ *   pixels with label == ignore_index are skipped (pass INT64_MIN for "no ignore");
+ *   bin b = [b/n_bins, (b+1)/n_bins) on float32 edges linspace(0,1,n_bins+1), last bin closed.
+ * Accumulates: count int64[n_bins], sum_correct f64[n_bins], sum_conf f64[n_bins]. */
+int slu_ece_update(const float* probs, const int64_t* labels, int B, int C, int HW, int64_t ignore_index,
+                   int n_bins, int64_t* count, double* sum_correct, double* sum_conf, slu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss (models/trainer.py:511-514): probs = softmax(logits);
+ *   nll_sum += sum_pixels -ln max(probs[label], clamp)     (caller divides by the pixel count)
+ * logits [B,C,HW], labels int64 [B,HW] in [0,C); probs out [B,C,HW] (may be NULL); nll_sum f64[1].
+ * ------------------------------------------------------------------------------------------ */
+int slu_softmax_nll_fwd(const float* logits, const int64_t* labels, int B, int C, int HW, float clamp,
+                        float* probs, double* nll_sum, slu_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLU_H_ */

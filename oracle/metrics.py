@@ -1,0 +1,82 @@
+"""Oracle: confusion-matrix IoU and top-label ECE in numpy.  TEST INFRASTRUCTURE ONLY.
+
+Follows ``src/models/evaluator.py:29-105`` (IoUEvaluator) and ``src/metrics/ece.py:54-168``
+(ECEAggregator: ``_to_probs``, ``update`` without the reservoir cap, ``_stats_df``, ``compute``).
+Integer work (confusion matrix, bin counts) is exact; pinned by ``tools/gen_golden.py`` against the
+imported reference classes.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def confusion_matrix(preds, targets, num_classes: int) -> np.ndarray:
+    """int64 [C,C], rows = ground truth, cols = prediction; out-of-range pairs dropped
+    (evaluator.py:45-53)."""
+    p = np.asarray(preds).reshape(-1).astype(np.int64)
+    t = np.asarray(targets).reshape(-1).astype(np.int64)
+    ok = (t >= 0) & (t < num_classes) & (p >= 0) & (p < num_classes)
+    idx = t[ok] * num_classes + p[ok]
+    return np.bincount(idx, minlength=num_classes * num_classes).reshape(num_classes, num_classes).astype(np.int64)
+
+
+def iou_from_confusion(cm, test_mask=None, ignore_gt=None):
+    """(mIoU, iou[C] float64 with NaN where TP+FP+FN == 0)  (evaluator.py:63-103)."""
+    cm = np.array(cm, dtype=np.float64)
+    c = cm.shape[0]
+    for r in ignore_gt or ():
+        if 0 <= r < c:
+            cm[r, :] = 0.0
+    tp = np.diag(cm)
+    denom = cm.sum(0) + cm.sum(1) - tp
+    iou = np.full(c, np.nan)
+    np.divide(tp, denom, out=iou, where=denom > 0)
+    mask = np.ones(c, bool) if test_mask is None else np.asarray(test_mask, bool)
+    sel = mask & np.isfinite(iou)
+    miou = float(np.mean(iou[sel])) if sel.any() else float("nan")
+    return miou, iou
+
+
+def top_label(probs, labels, ignore_index=None, mode="probs", eps=1e-12):
+    """(conf float32[n], correct bool[n]) over valid pixels in NCHW scan order (ece.py:55-84)."""
+    p = np.asarray(probs, dtype=np.float32)
+    if mode == "probs":
+        p = np.maximum(p, 0)
+        p = p / np.maximum(p.sum(axis=1, keepdims=True), np.float32(eps))
+    elif mode == "alpha":
+        p = p / (p.sum(axis=1, keepdims=True) + np.float32(eps))
+    elif mode == "logits":
+        z = p - p.max(axis=1, keepdims=True)
+        e = np.exp(z)
+        p = e / e.sum(axis=1, keepdims=True)
+    else:
+        raise ValueError(mode)
+    conf = p.max(axis=1)
+    pred = p.argmax(axis=1)
+    lab = np.asarray(labels).astype(np.int64)
+    valid = np.ones_like(lab, bool) if ignore_index is None else lab != ignore_index
+    conf = np.clip(conf[valid].astype(np.float32), 0.0, 1.0)
+    return conf, pred[valid] == lab[valid]
+
+
+def ece_bins(conf, correct, n_bins: int = 15):
+    """(n int64[n_bins], sum_correct float64, sum_conf float64): uniform float32 edges, last bin
+    right-inclusive -- the np.histogram call of ece.py:136-140."""
+    edges = np.linspace(0.0, 1.0, n_bins + 1, dtype=np.float32)
+    edges[0], edges[-1] = 0.0, 1.0
+    conf = np.asarray(conf, np.float32)
+    n = np.histogram(conf, bins=edges)[0].astype(np.int64)
+    acc_s = np.histogram(conf, bins=edges, weights=np.asarray(correct, np.float32))[0]
+    conf_s = np.histogram(conf, bins=edges, weights=conf)[0]
+    return n, acc_s.astype(np.float64), conf_s.astype(np.float64)
+
+
+def ece_from_bins(n, acc_s, conf_s):
+    """(ece, mce)  (ece.py:161-169)."""
+    n = np.asarray(n, np.float64)
+    if n.sum() == 0:
+        return float("nan"), float("nan")
+    acc = np.divide(acc_s, n, out=np.zeros_like(n), where=n > 0)
+    conf = np.divide(conf_s, n, out=np.zeros_like(n), where=n > 0)
+    gap = np.abs(acc - conf)
+    return float(np.sum(n / max(1.0, n.sum()) * gap)), float(np.max(gap[n > 0]))

@@ -1,0 +1,94 @@
+"""ctypes binding of libslu_hip.so (C ABI declared in include/slu.h).
+
+There is deliberately NO fallback: if the shared library is missing or does not export the ABI
+version this package was written against, importing the ops raises.  torch is used only to own
+device memory and to name the HIP stream the launches go on.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+MAX_SRC = 3
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
+
+c_f32p = C.c_void_p
+c_i64p = C.c_void_p
+c_f64p = C.c_void_p
+c_stream = C.c_void_p
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("C", C.c_int32), ("pixel_shuffle", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("src", ConvSrc * MAX_SRC),
+        ("nsrc", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("ksize", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
+        ("ck", C.c_int32),
+        ("wpack", C.c_void_p), ("bias", C.c_void_p),
+        ("has_act", C.c_int32), ("slope", C.c_float),
+        ("bn_a", C.c_void_p), ("bn_b", C.c_void_p),
+        ("resid", C.c_void_p), ("out", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/slu.h declares
+SIGNATURES = {
+    "slu_abi_version": (C.c_int, []),
+    "slu_strerror": (C.c_char_p, [C.c_int]),
+    "slu_conv_ck": (C.c_int, [C.c_int]),
+    "slu_packed_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "slu_pack_conv_weight": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "slu_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), c_stream]),
+    "slu_conv2d_kernel_name": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, C.c_size_t]),
+    "slu_bn_fold": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_int, c_f32p, c_f32p, c_stream]),
+    "slu_avgpool3s2_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_mc_reduce": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_f32p, c_f32p,
+                                c_i64p, c_stream]),
+    "slu_softmax_entropy": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_f32p, c_i64p,
+                                      c_stream]),
+    "slu_confusion_update": (C.c_int, [c_i64p, c_i64p, C.c_int64, C.c_int, c_i64p, c_stream]),
+    "slu_ece_update": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, c_i64p, c_f64p,
+                                 c_f64p, c_stream]),
+    "slu_softmax_nll_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_f64p,
+                                      c_stream]),
+}
+
+_lib = None
+
+
+class SluError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it is absent or ABI-incompatible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SluError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C semanticlidarunc_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    v = lib.slu_abi_version()
+    if v != ABI_VERSION:
+        raise SluError(f"libslu_hip.so ABI version {v} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().slu_strerror(code).decode()
+        raise SluError(f"{what}: {msg} (code {code})")

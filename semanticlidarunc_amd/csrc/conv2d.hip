@@ -1,0 +1,323 @@
+// Fused direct convolution for 2-D range images on gfx950 (MI355X), fp32 in / fp32 out, exact fp32
+// arithmetic on the matrix cores (v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain).
+//
+// Replaces, per call, the chain  torch.cat / nn.PixelShuffle(2) / nn.Dropout2d -> nn.Conv2d ->
+// nn.LeakyReLU -> nn.BatchNorm2d(eval) -> residual add  of the reference's SalsaNext blocks
+// (src/baselines/SalsaNext/SalsaNext.py:25-39, :73-109, :142-170, :213).
+//
+// Mapping (implicit GEMM, one 64-lane wave = one or more 32x32 MFMA tiles):
+//   M = output channels   (A operand = weights, pre-packed in fragment order by slu_pack_conv_weight)
+//   N = 32 azimuth-adjacent pixels of one image row (B operand, read from an LDS input tile)
+//   K = (input channel, tap) pairs, two input channels per MFMA (lane>>5 selects the channel)
+// The D fragment has the pixel on the lane (col = lane&31) and the output channel on the register,
+// so every store instruction writes two 128-byte row segments (coalesced along azimuth).
+//
+// Work decomposition: a workgroup owns TH rows x 64 columns of one image and WM*MB*32 output
+// channels; per K-chunk (CK input channels) it stages the (TH+2*pad) x (64+2*pad) halo tile of
+// each channel and the matching weight fragments into LDS, then every wave runs KS*KS*CK/2 K-steps.
+#include <stdio.h>
+
+#include "slu_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct SrcDev {
+  const float* ptr;
+  const float* scale;
+  int C;       // channels of the stored tensor
+  int ps;      // pixel-shuffle source
+  int cbeg;    // first conv-input channel contributed
+  int ccount;  // number of conv-input channels contributed
+};
+
+struct ConvArgs {
+  SrcDev src[SLU_MAX_SRC];
+  int nsrc;
+  int N, H, W, Cin, Cout;
+  int tiles_x, tiles_y, nchunks, nmblk;
+  const float* wpack;
+  const float* bias;
+  const float* bn_a;
+  const float* bn_b;
+  const float* resid;
+  float* out;
+  float slope;
+  int has_act;
+};
+
+__device__ __forceinline__ float load_input(const ConvArgs& a, int n, int cg, int gy, int gx) {
+#pragma unroll
+  for (int s = 0; s < SLU_MAX_SRC; ++s) {
+    if (s < a.nsrc) {
+      const SrcDev& S = a.src[s];
+      const int cl = cg - S.cbeg;
+      if (cl >= 0 && cl < S.ccount) {
+        float v;
+        int cs;
+        if (!S.ps) {
+          cs = cl;
+          v = S.ptr[(((size_t)n * S.C + cs) * a.H + gy) * a.W + gx];
+        } else {
+          cs = cl * 4 + ((gy & 1) << 1) + (gx & 1);
+          v = S.ptr[(((size_t)n * S.C + cs) * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)];
+        }
+        if (S.scale) v *= S.scale[(size_t)n * S.C + cs];
+        return v;
+      }
+    }
+  }
+  return 0.0f;
+}
+
+template <int KS, int DIL, int PAD, int CK, int MB, int WM, int WN, int RPW>
+__global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : 4) void conv_fwd_kernel(const ConvArgs a) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TW = 64, TH = WN * RPW, NB = 2 * RPW;
+  constexpr int LW = TW + 2 * PAD, LH = TH + 2 * PAD;
+  constexpr int PLANE = LH * LW;
+  constexpr int HALF = CK / 2;
+  constexpr int KSTEPS = KS * KS * HALF;
+  constexpr int MBLK = WM * MB;
+
+  __shared__ float s_in[CK * PLANE];
+  __shared__ __attribute__((aligned(16))) float s_w[MBLK * KSTEPS * 64];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int t = blockIdx.x;
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int n = t / a.tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int mblk0 = blockIdx.y * MBLK;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
+
+  const int hh = lane >> 5, jj = lane & 31;
+  const int bbase = hh * PLANE + (wn * RPW) * LW + jj;
+  const int abase = (wm * MB) * KSTEPS * 64 + lane;
+
+  for (int q = 0; q < a.nchunks; ++q) {
+    __syncthreads();
+    // ---- stage the halo tile of CK input channels (zero outside the image / beyond Cin) ----
+    for (int e = tid; e < CK * PLANE; e += NT) {
+      const int ci = e / PLANE;
+      const int rem = e - ci * PLANE;
+      const int r = rem / LW;
+      const int c = rem - r * LW;
+      const int gy = y0 + r - PAD, gx = x0 + c - PAD, cg = q * CK + ci;
+      float v = 0.0f;
+      if (cg < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = load_input(a, n, cg, gy, gx);
+      s_in[e] = v;
+    }
+    // ---- stage the A fragments of this chunk: MBLK contiguous runs of KSTEPS*64 floats ----
+    for (int e = tid; e < MBLK * KSTEPS * 16; e += NT) {
+      const int m = e / (KSTEPS * 16);
+      const int r = e - m * (KSTEPS * 16);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int mg = mblk0 + m;
+      if (mg < a.nmblk)
+        v = reinterpret_cast<const float4*>(a.wpack + ((size_t)mg * a.nchunks + q) * (KSTEPS * 64))[r];
+      reinterpret_cast<float4*>(s_w)[e] = v;
+    }
+    __syncthreads();
+    // ---- K-steps ----
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      const int tap = s / HALF, pp = s % HALF;
+      const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
+      float av[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) av[i] = s_w[abase + (i * KSTEPS + s) * 64];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int rr = b >> 1, cb = b & 1;
+        const float bv = s_in[bbase + (2 * pp) * PLANE + (rr + dy) * LW + cb * 32 + dx];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][b], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: bias, LeakyReLU, folded BatchNorm, residual, store (2 x 128 B per instruction) ----
+  const size_t plane = (size_t)a.H * a.W;
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int mg = mblk0 + wm * MB + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = mg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (co >= a.Cout) continue;
+      const float bias = a.bias ? a.bias[co] : 0.0f;
+      const float ga = a.bn_a ? a.bn_a[co] : 1.0f;
+      const float gb = a.bn_a ? a.bn_b[co] : 0.0f;
+      const size_t cbase = ((size_t)n * a.Cout + co) * plane;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int gy = y0 + wn * RPW + (b >> 1), gx = x0 + (b & 1) * 32 + jj;
+        if (gy < a.H && gx < a.W) {
+          float v = acc[i][b][r] + bias;
+          if (a.has_act) v = v > 0.0f ? v : v * a.slope;
+          if (a.bn_a) v = v * ga + gb;
+          const size_t o = cbase + (size_t)gy * a.W + gx;
+          if (a.resid) v += a.resid[o];
+          a.out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int ks, int ck, int nchunks,
+                                   size_t total, float* __restrict__ out) {
+  const int half = ck / 2, ksteps = ks * ks * half;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(e & 63);
+    size_t r = e >> 6;
+    const int s = (int)(r % ksteps);
+    r /= ksteps;
+    const int q = (int)(r % nchunks);
+    const int m = (int)(r / nchunks);
+    const int tap = s / half, pp = s % half;
+    const int ci = q * ck + 2 * pp + (lane >> 5);
+    const int co = m * 32 + (lane & 31);
+    float v = 0.0f;
+    if (co < cout && ci < cin) v = w[((size_t)co * cin + ci) * (ks * ks) + tap];
+    out[e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------------------------
+enum TileCfg { M32_TH8 = 0, M64_TH8, M128_TH4, M32_TH4, M64_TH4 };
+
+template <int KS, int DIL, int PAD, int CK, int MB, int WM, int WN, int RPW>
+int launch_cfg(ConvArgs& a, hipStream_t st) {
+  constexpr int TH = WN * RPW, MBLK = WM * MB;
+  a.tiles_x = (a.W + 63) / 64;
+  a.tiles_y = (a.H + TH - 1) / TH;
+  const long long gx = (long long)a.tiles_x * a.tiles_y * a.N;
+  const int gy = (a.nmblk + MBLK - 1) / MBLK;
+  if (gx <= 0 || gx > 0x7fffffffLL || gy > 65535) return SLU_EUNSUPPORTED;
+  hipLaunchKernelGGL((conv_fwd_kernel<KS, DIL, PAD, CK, MB, WM, WN, RPW>), dim3((unsigned)gx, (unsigned)gy), dim3(64 * WM * WN),
+                     0, st, a);
+  SLU_CHECK_LAUNCH();
+}
+
+template <int KS, int DIL, int PAD, int CK>
+int launch_family(ConvArgs& a, int cfg, hipStream_t st) {
+  switch (cfg) {
+    case M32_TH8:  return launch_cfg<KS, DIL, PAD, CK, 1, 1, 4, 2>(a, st);
+    case M64_TH8:  return launch_cfg<KS, DIL, PAD, CK, 2, 1, 4, 2>(a, st);
+    case M128_TH4: return launch_cfg<KS, DIL, PAD, CK, 2, 2, 2, 2>(a, st);
+    case M32_TH4:  return launch_cfg<KS, DIL, PAD, CK, 1, 1, 4, 1>(a, st);
+    case M64_TH4:  return launch_cfg<KS, DIL, PAD, CK, 2, 1, 4, 1>(a, st);
+  }
+  return SLU_EUNSUPPORTED;
+}
+
+long long wg_count(const ConvArgs& a, int th, int mblk) {
+  return (long long)a.N * ((a.H + th - 1) / th) * ((a.W + 63) / 64) * ((a.nmblk + mblk - 1) / mblk);
+}
+
+// Tile choice: the biggest tile that still gives >= 2 workgroups per CU (256 CUs); below that,
+// shrink rows first (TH 8 -> 4), then the channel tile, so small feature maps still fill the chip.
+int choose_cfg(const ConvArgs& a) {
+  const long long want = 512;
+  if (a.nmblk >= 4) {
+    if (wg_count(a, 4, 4) >= want) return M128_TH4;
+    if (wg_count(a, 4, 2) >= want) return M64_TH4;
+    return M32_TH4;
+  }
+  if (a.nmblk >= 2) {
+    if (a.H >= 8 && wg_count(a, 8, 2) >= want) return M64_TH8;
+    if (wg_count(a, 4, 2) >= want) return M64_TH4;
+    return M32_TH4;
+  }
+  if (a.H >= 8 && wg_count(a, 8, 1) >= want) return M32_TH8;
+  return M32_TH4;
+}
+
+}  // namespace
+
+extern "C" int slu_conv_ck(int ksize) { return ksize == 1 ? 16 : 8; }
+
+extern "C" size_t slu_packed_weight_floats(int cout, int cin, int ksize, int ck) {
+  if (cout <= 0 || cin <= 0 || ksize <= 0 || ck <= 0 || (ck & 1)) return 0;
+  const size_t nmblk = (cout + 31) / 32, nchunks = (cin + ck - 1) / ck;
+  return nmblk * nchunks * (size_t)(ksize * ksize * ck / 2) * 64;
+}
+
+extern "C" int slu_pack_conv_weight(const float* w, int cout, int cin, int ksize, int ck, float* out, slu_stream_t stream) {
+  if (!w || !out) return SLU_EINVAL;
+  const size_t total = slu_packed_weight_floats(cout, cin, ksize, ck);
+  if (total == 0) return SLU_EINVAL;
+  const int nchunks = (cin + ck - 1) / ck;
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, slu_stream(stream), w, cout, cin, ksize, ck, nchunks, total, out);
+  SLU_CHECK_LAUNCH();
+}
+
+static int fill_args(const slu_conv_desc* d, ConvArgs& a) {
+  if (!d || !d->out || !d->wpack || d->nsrc < 1 || d->nsrc > SLU_MAX_SRC) return SLU_EINVAL;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return SLU_EINVAL;
+  if (d->bn_a && !d->bn_b) return SLU_EINVAL;
+  int c = 0;
+  for (int s = 0; s < d->nsrc; ++s) {
+    const slu_conv_src& S = d->src[s];
+    if (!S.ptr || S.C <= 0) return SLU_EINVAL;
+    if (S.pixel_shuffle && ((S.C & 3) || (d->H & 1) || (d->W & 1))) return SLU_EINVAL;
+    a.src[s].ptr = S.ptr;
+    a.src[s].scale = S.scale;
+    a.src[s].C = S.C;
+    a.src[s].ps = S.pixel_shuffle ? 1 : 0;
+    a.src[s].cbeg = c;
+    a.src[s].ccount = S.pixel_shuffle ? S.C / 4 : S.C;
+    c += a.src[s].ccount;
+  }
+  if (c != d->Cin) return SLU_EINVAL;
+  if (d->ck != slu_conv_ck(d->ksize)) return SLU_EINVAL;
+  a.nsrc = d->nsrc;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+  a.nchunks = (d->Cin + d->ck - 1) / d->ck;
+  a.nmblk = (d->Cout + 31) / 32;
+  a.wpack = d->wpack; a.bias = d->bias; a.bn_a = d->bn_a; a.bn_b = d->bn_b; a.resid = d->resid; a.out = d->out;
+  a.slope = d->slope; a.has_act = d->has_act;
+  return SLU_OK;
+}
+
+extern "C" int slu_conv2d_fwd(const slu_conv_desc* d, slu_stream_t stream) {
+  ConvArgs a{};
+  const int rc = fill_args(d, a);
+  if (rc != SLU_OK) return rc;
+  const int cfg = choose_cfg(a);
+  hipStream_t st = slu_stream(stream);
+  if (d->ksize == 1 && d->dil == 1 && d->pad == 0) return launch_family<1, 1, 0, 16>(a, cfg, st);
+  if (d->ksize == 3 && d->dil == 1 && d->pad == 1) return launch_family<3, 1, 1, 8>(a, cfg, st);
+  if (d->ksize == 3 && d->dil == 2 && d->pad == 2) return launch_family<3, 2, 2, 8>(a, cfg, st);
+  if (d->ksize == 2 && d->dil == 2 && d->pad == 1) return launch_family<2, 2, 1, 8>(a, cfg, st);
+  return SLU_EUNSUPPORTED;
+}
+
+// Template arguments of the instantiation slu_conv2d_fwd would launch for this descriptor, in the
+// order rocprofv3 prints them: "conv_fwd_kernel<KS, DIL, PAD, CK, MB, WM, WN, RPW>".
+extern "C" int slu_conv2d_kernel_name(const slu_conv_desc* d, char* buf, size_t buflen) {
+  if (!buf || buflen < 48) return SLU_EINVAL;
+  ConvArgs a{};
+  const int rc = fill_args(d, a);
+  if (rc != SLU_OK) return rc;
+  static const int kTile[5][4] = {{1, 1, 4, 2}, {2, 1, 4, 2}, {2, 2, 2, 2}, {1, 1, 4, 1}, {2, 1, 4, 1}};
+  const int* t = kTile[choose_cfg(a)];
+  snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", d->ksize, d->dil, d->pad, d->ck, t[0], t[1], t[2], t[3]);
+  return SLU_OK;
+}

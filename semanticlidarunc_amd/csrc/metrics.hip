@@ -1,0 +1,160 @@
+// On-device metric accumulators: confusion matrix (IoU) and top-label calibration bins (ECE),
+// plus the softmax + NLL reduction of the SalsaNext loss.  Integer counts are exact (LDS integer
+// histograms -> one 64-bit global atomic per non-empty bin per workgroup).
+#include "slu_common.h"
+
+namespace {
+
+// models/evaluator.py:45-53 : idx = t*C + p ; bincount
+__global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restrict__ preds, const int64_t* __restrict__ targets,
+                                                        int64_t n, int C, unsigned long long* __restrict__ cm) {
+  __shared__ unsigned int hist[32 * 32];
+  const int cc = C * C;
+  for (int i = threadIdx.x; i < cc; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = targets[e], p = preds[e];
+    if (t >= 0 && t < C && p >= 0 && p < C) atomicAdd(&hist[(int)t * C + (int)p], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cc; i += blockDim.x)
+    if (hist[i]) atomicAdd(&cm[i], (unsigned long long)hist[i]);
+}
+
+// metrics/ece.py:55-84 ('probs' mode) + :136-140 (np.histogram on float32 linspace edges)
+template <int CMAX>
+__global__ __launch_bounds__(256) void ece_kernel(const float* __restrict__ probs, const int64_t* __restrict__ labels, int B, int C,
+                                                  int HW, int64_t ignore_index, int n_bins,
+                                                  unsigned long long* __restrict__ count, double* __restrict__ sum_correct,
+                                                  double* __restrict__ sum_conf) {
+  __shared__ unsigned int s_n[64], s_ok[64];
+  __shared__ float s_conf[64];
+  __shared__ float s_edge[65];
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) { s_n[i] = 0; s_ok[i] = 0; s_conf[i] = 0.0f; }
+  for (int i = threadIdx.x; i <= n_bins; i += blockDim.x)
+    s_edge[i] = (i == n_bins) ? 1.0f : (float)((double)i * (1.0 / (double)n_bins));  // np.linspace(0,1,n+1,float32)
+  __syncthreads();
+  const size_t npix = (size_t)B * HW;
+  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+    const int64_t lab = labels[pix];
+    if (lab == ignore_index) continue;
+    const int b = (int)(pix / HW);
+    const int hw = (int)(pix - (size_t)b * HW);
+    const float* src = probs + (size_t)b * C * (size_t)HW + hw;
+    float s = 0.0f, best = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+        const float p = fmaxf(src[(size_t)c * HW], 0.0f);
+        s += p;
+        if (p > best) { best = p; arg = c; }
+      }
+    float conf = best / fmaxf(s, 1e-12f);
+    conf = fminf(fmaxf(conf, 0.0f), 1.0f);
+    int bin = (int)(conf * (float)n_bins);
+    bin = bin < 0 ? 0 : (bin > n_bins - 1 ? n_bins - 1 : bin);
+    while (bin > 0 && conf < s_edge[bin]) --bin;
+    while (bin < n_bins - 1 && conf >= s_edge[bin + 1]) ++bin;
+    atomicAdd(&s_n[bin], 1u);
+    if ((int64_t)arg == lab) atomicAdd(&s_ok[bin], 1u);
+    atomicAdd(&s_conf[bin], conf);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_bins; i += blockDim.x)
+    if (s_n[i]) {
+      atomicAdd(&count[i], (unsigned long long)s_n[i]);
+      atomicAdd(&sum_correct[i], (double)s_ok[i]);
+      atomicAdd(&sum_conf[i], (double)s_conf[i]);
+    }
+}
+
+// models/trainer.py:511-514 : probs = softmax(logits); -log(max(probs[y], clamp)) summed over pixels
+template <int CMAX>
+__global__ __launch_bounds__(256) void softmax_nll_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                          int B, int C, int HW, float clampv, float* __restrict__ probs,
+                                                          double* __restrict__ nll_sum) {
+  __shared__ double s_part[4];
+  const size_t npix = (size_t)B * HW;
+  double local = 0.0;
+  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(pix / HW);
+    const int hw = (int)(pix - (size_t)b * HW);
+    const float* src = logits + (size_t)b * C * (size_t)HW + hw;
+    float x[CMAX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      x[c] = (c < C) ? src[(size_t)c * HW] : -INFINITY;
+      m = fmaxf(m, x[c]);
+    }
+    float se = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) { x[c] = expf(x[c] - m); se += x[c]; }
+    const int64_t lab = labels[pix];
+    float py = 1.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+        const float p = x[c] / se;
+        if (probs) probs[((size_t)b * C + c) * HW + hw] = p;
+        if ((int64_t)c == lab) py = p;
+      }
+    if (lab >= 0 && lab < C) local += (double)(-logf(fmaxf(py, clampv)));
+  }
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_part[w];
+    atomicAdd(nll_sum, tot);
+  }
+}
+
+inline unsigned grid_for(size_t n, unsigned cap) {
+  const size_t nb = (n + 255) / 256;
+  return (unsigned)(nb > cap ? cap : (nb ? nb : 1));
+}
+
+}  // namespace
+
+extern "C" int slu_confusion_update(const int64_t* preds, const int64_t* targets, int64_t n, int C, int64_t* confmat,
+                                    slu_stream_t stream) {
+  if (!preds || !targets || !confmat || n < 0 || C <= 0) return SLU_EINVAL;
+  if (C > 32) return SLU_EUNSUPPORTED;
+  if (n == 0) return SLU_OK;
+  hipLaunchKernelGGL(confusion_kernel, dim3(grid_for((size_t)n, 1024)), dim3(256), 0, slu_stream(stream), preds, targets, n, C,
+                     reinterpret_cast<unsigned long long*>(confmat));
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_ece_update(const float* probs, const int64_t* labels, int B, int C, int HW, int64_t ignore_index, int n_bins,
+                              int64_t* count, double* sum_correct, double* sum_conf, slu_stream_t stream) {
+  if (!probs || !labels || !count || !sum_correct || !sum_conf || B <= 0 || C <= 0 || HW <= 0) return SLU_EINVAL;
+  if (C > 32 || n_bins < 2 || n_bins > 64) return SLU_EUNSUPPORTED;
+  const unsigned g = grid_for((size_t)B * HW, 1024);
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(count);
+  if (C <= 20)
+    hipLaunchKernelGGL(ece_kernel<20>, dim3(g), dim3(256), 0, slu_stream(stream), probs, labels, B, C, HW, ignore_index, n_bins, cnt,
+                       sum_correct, sum_conf);
+  else
+    hipLaunchKernelGGL(ece_kernel<32>, dim3(g), dim3(256), 0, slu_stream(stream), probs, labels, B, C, HW, ignore_index, n_bins, cnt,
+                       sum_correct, sum_conf);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_softmax_nll_fwd(const float* logits, const int64_t* labels, int B, int C, int HW, float clampv, float* probs,
+                                   double* nll_sum, slu_stream_t stream) {
+  if (!logits || !labels || !nll_sum || B <= 0 || C <= 0 || HW <= 0) return SLU_EINVAL;
+  if (C > 32) return SLU_EUNSUPPORTED;
+  const unsigned g = grid_for((size_t)B * HW, 2048);
+  if (C <= 20)
+    hipLaunchKernelGGL(softmax_nll_kernel<20>, dim3(g), dim3(256), 0, slu_stream(stream), logits, labels, B, C, HW, clampv, probs,
+                       nll_sum);
+  else
+    hipLaunchKernelGGL(softmax_nll_kernel<32>, dim3(g), dim3(256), 0, slu_stream(stream), logits, labels, B, C, HW, clampv, probs,
+                       nll_sum);
+  SLU_CHECK_LAUNCH();
+}

@@ -1,0 +1,255 @@
+"""Thin, checked Python wrappers over the C ABI (include/slu.h).
+
+torch tensors own the memory; every function validates device / dtype / contiguity / shape on the
+host before the launch (a wrong shape must never reach a hand-written kernel) and launches on
+torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+INT64_MIN = -(2 ** 63)
+
+# bench.py sets this to a list to collect (kernel name, algorithmic flops, algorithmic bytes, ev0, ev1)
+# per conv launch; None (the default) adds nothing to the launch path.
+TIMING = None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on '{t.device}'; the HIP path only runs on a GPU (no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+class ConvSource(NamedTuple):
+    """One channel-concatenated input of a fused conv."""
+    tensor: torch.Tensor                    # [N,C,H,W], or [N,C,H/2,W/2] when pixel_shuffle
+    scale: Optional[torch.Tensor] = None    # [N,C] multiplier (folded Dropout2d) or None
+    pixel_shuffle: bool = False
+
+
+def conv_ck(ksize: int) -> int:
+    return _lib.load().slu_conv_ck(ksize)
+
+
+def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
+    """OIHW fp32 weight -> MFMA A-fragment image (re-run after every weight update)."""
+    _req(weight, "weight")
+    if weight.dim() != 4 or weight.shape[2] != weight.shape[3]:
+        raise RuntimeError(f"weight: expected [Cout,Cin,k,k], got {tuple(weight.shape)}")
+    lib = _lib.load()
+    cout, cin, ks, _ = weight.shape
+    ck = lib.slu_conv_ck(ks)
+    n = lib.slu_packed_weight_floats(cout, cin, ks, ck)
+    if n == 0:
+        raise RuntimeError("pack_conv_weight: unsupported weight shape")
+    out = torch.empty(n, dtype=torch.float32, device=weight.device)
+    check(lib.slu_pack_conv_weight(weight.data_ptr(), cout, cin, ks, ck, out.data_ptr(), _stream()), "slu_pack_conv_weight")
+    return out
+
+
+def bn_fold(gamma, beta, mean, var, eps: float):
+    """(a, b) with  a*x + b == eval BatchNorm(x)."""
+    c = gamma.numel()
+    for t, nme in ((gamma, "gamma"), (beta, "beta"), (mean, "running_mean"), (var, "running_var")):
+        _req(t, nme)
+        if t.numel() != c:
+            raise RuntimeError("bn_fold: size mismatch")
+    a = torch.empty(c, dtype=torch.float32, device=gamma.device)
+    b = torch.empty_like(a)
+    check(_lib.load().slu_bn_fold(gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(), float(eps), c,
+                                  a.data_ptr(), b.data_ptr(), _stream()), "slu_bn_fold")
+    return a, b
+
+
+def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksize: int, dil: int, pad: int,
+                 bias: Optional[torch.Tensor] = None, slope: Optional[float] = None,
+                 bn_a: Optional[torch.Tensor] = None, bn_b: Optional[torch.Tensor] = None,
+                 resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = resid + bn_a * leaky(conv(cat(srcs)) + bias) + bn_b   (see slu_conv2d_fwd)."""
+    lib = _lib.load()
+    if not 1 <= len(srcs) <= _lib.MAX_SRC:
+        raise RuntimeError(f"conv2d_fused: 1..{_lib.MAX_SRC} sources supported, got {len(srcs)}")
+    d = ConvDesc()
+    n = h = w = None
+    cin = 0
+    keep = []
+    for i, s in enumerate(srcs):
+        t = _req(s.tensor, f"src[{i}]")
+        if t.dim() != 4:
+            raise RuntimeError(f"src[{i}]: expected NCHW, got {tuple(t.shape)}")
+        sn, sc, sh, sw = t.shape
+        if s.pixel_shuffle:
+            if sc % 4:
+                raise RuntimeError(f"src[{i}]: PixelShuffle(2) needs C % 4 == 0")
+            sh, sw, contributed = sh * 2, sw * 2, sc // 4
+        else:
+            contributed = sc
+        if n is None:
+            n, h, w = sn, sh, sw
+        elif (sn, sh, sw) != (n, h, w):
+            raise RuntimeError(f"src[{i}]: spatial/batch size {(sn, sh, sw)} != {(n, h, w)}")
+        if s.scale is not None:
+            _req(s.scale, f"src[{i}].scale")
+            if tuple(s.scale.shape) != (sn, sc):
+                raise RuntimeError(f"src[{i}].scale: expected {(sn, sc)}, got {tuple(s.scale.shape)}")
+        d.src[i].ptr = t.data_ptr()
+        d.src[i].scale = _ptr(s.scale)
+        d.src[i].C = sc
+        d.src[i].pixel_shuffle = 1 if s.pixel_shuffle else 0
+        cin += contributed
+        keep.append(t)
+    ck = lib.slu_conv_ck(ksize)
+    _req(wpack, "wpack")
+    if wpack.numel() != lib.slu_packed_weight_floats(cout, cin, ksize, ck):
+        raise RuntimeError(f"wpack: {wpack.numel()} floats does not match Cout={cout} Cin={cin} k={ksize}")
+    for t, nme in ((bias, "bias"), (bn_a, "bn_a"), (bn_b, "bn_b")):
+        if t is not None:
+            _req(t, nme)
+            if t.numel() != cout:
+                raise RuntimeError(f"{nme}: expected {cout} elements, got {t.numel()}")
+    if (bn_a is None) != (bn_b is None):
+        raise RuntimeError("bn_a and bn_b must be given together")
+    if out is None:
+        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=keep[0].device)
+    else:
+        _req(out, "out")
+        if tuple(out.shape) != (n, cout, h, w):
+            raise RuntimeError(f"out: expected {(n, cout, h, w)}, got {tuple(out.shape)}")
+    if resid is not None:
+        _req(resid, "resid")
+        if tuple(resid.shape) != (n, cout, h, w):
+            raise RuntimeError(f"resid: expected {(n, cout, h, w)}, got {tuple(resid.shape)}")
+    d.nsrc = len(srcs)
+    d.N, d.H, d.W, d.Cin, d.Cout = n, h, w, cin, cout
+    d.ksize, d.dil, d.pad, d.ck = ksize, dil, pad, ck
+    d.wpack, d.bias = wpack.data_ptr(), _ptr(bias)
+    d.has_act, d.slope = (0, 0.0) if slope is None else (1, float(slope))
+    d.bn_a, d.bn_b, d.resid, d.out = _ptr(bn_a), _ptr(bn_b), _ptr(resid), out.data_ptr()
+    if TIMING is None:
+        check(lib.slu_conv2d_fwd(C.byref(d), _stream()), "slu_conv2d_fwd")
+        return out
+    # measurement mode (bench.py): HIP events on the launch stream around this one kernel
+    buf = C.create_string_buffer(64)
+    check(lib.slu_conv2d_kernel_name(C.byref(d), buf, 64), "slu_conv2d_kernel_name")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.slu_conv2d_fwd(C.byref(d), _stream()), "slu_conv2d_fwd")
+    e1.record()
+    flops = 2.0 * cin * cout * ksize * ksize * n * h * w
+    nbytes = 4.0 * (n * h * w * (cin + cout) + cout * cin * ksize * ksize)
+    TIMING.append((buf.value.decode(), flops, nbytes, e0, e1))
+    return out
+
+
+def avgpool3s2(x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, "x")
+    n, c, h, w = x.shape
+    if scale is not None:
+        _req(scale, "scale")
+        if tuple(scale.shape) != (n, c):
+            raise RuntimeError(f"scale: expected {(n, c)}, got {tuple(scale.shape)}")
+    y = torch.empty((n, c, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_avgpool3s2_fwd(x.data_ptr(), _ptr(scale), y.data_ptr(), n, c, h, w, _stream()), "slu_avgpool3s2_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# uncertainty / loss / metrics
+# ------------------------------------------------------------------------------------------------
+def mc_reduce(mc_logits: torch.Tensor, eps: float = 1e-12):
+    """[T,B,C,H,W] logits -> (p_bar[B,C,H,W], H_norm[B,H,W], MI_norm[B,H,W], preds[B,H,W] int64)."""
+    _req(mc_logits, "mc_logits")
+    if mc_logits.dim() != 5:
+        raise RuntimeError(f"mc_logits: expected [T,B,C,H,W], got {tuple(mc_logits.shape)}")
+    t, b, c, h, w = mc_logits.shape
+    dev = mc_logits.device
+    p_bar = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
+    hn = torch.empty((b, h, w), dtype=torch.float32, device=dev)
+    mi = torch.empty((b, h, w), dtype=torch.float32, device=dev)
+    preds = torch.empty((b, h, w), dtype=torch.int64, device=dev)
+    check(_lib.load().slu_mc_reduce(mc_logits.data_ptr(), t, b, c, h * w, float(eps), p_bar.data_ptr(), hn.data_ptr(),
+                                    mi.data_ptr(), preds.data_ptr(), _stream()), "slu_mc_reduce")
+    return p_bar, hn, mi, preds
+
+
+def softmax_entropy(logits: torch.Tensor, eps: float = 1e-8):
+    """[B,C,H,W] logits -> (probs, H_norm[B,H,W], preds[B,H,W] int64)."""
+    _req(logits, "logits")
+    b, c, h, w = logits.shape
+    dev = logits.device
+    probs = torch.empty_like(logits)
+    hn = torch.empty((b, h, w), dtype=torch.float32, device=dev)
+    preds = torch.empty((b, h, w), dtype=torch.int64, device=dev)
+    check(_lib.load().slu_softmax_entropy(logits.data_ptr(), b, c, h * w, float(eps), probs.data_ptr(), hn.data_ptr(),
+                                          preds.data_ptr(), _stream()), "slu_softmax_entropy")
+    return probs, hn, preds
+
+
+def confusion_update(confmat: torch.Tensor, preds: torch.Tensor, targets: torch.Tensor) -> None:
+    """confmat[C,C] int64 (rows = GT) += bincount(t*C+p) over in-range pairs, in place."""
+    _req(confmat, "confmat", torch.int64)
+    _req(preds, "preds", torch.int64)
+    _req(targets, "targets", torch.int64)
+    if preds.numel() != targets.numel():
+        raise RuntimeError("preds/targets size mismatch")
+    c = confmat.shape[0]
+    if confmat.dim() != 2 or confmat.shape[1] != c:
+        raise RuntimeError("confmat must be [C,C]")
+    check(_lib.load().slu_confusion_update(preds.data_ptr(), targets.data_ptr(), preds.numel(), c, confmat.data_ptr(),
+                                           _stream()), "slu_confusion_update")
+
+
+def ece_update(probs, labels, count, sum_correct, sum_conf, ignore_index=None) -> None:
+    """Accumulate top-label calibration bins in place (count int64[nb], sums float64[nb])."""
+    _req(probs, "probs")
+    _req(labels, "labels", torch.int64)
+    _req(count, "count", torch.int64)
+    _req(sum_correct, "sum_correct", torch.float64)
+    _req(sum_conf, "sum_conf", torch.float64)
+    b, c, h, w = probs.shape
+    if labels.numel() != b * h * w:
+        raise RuntimeError("labels size mismatch")
+    nb = count.numel()
+    if sum_correct.numel() != nb or sum_conf.numel() != nb:
+        raise RuntimeError("bin accumulator size mismatch")
+    ign = INT64_MIN if ignore_index is None else int(ignore_index)
+    check(_lib.load().slu_ece_update(probs.data_ptr(), labels.data_ptr(), b, c, h * w, ign, nb, count.data_ptr(),
+                                     sum_correct.data_ptr(), sum_conf.data_ptr(), _stream()), "slu_ece_update")
+
+
+def softmax_nll(logits: torch.Tensor, labels: torch.Tensor, clamp: float = 1e-8, want_probs: bool = True):
+    """(probs or None, nll_sum float64[1]) : sum over pixels of -ln max(softmax(logits)[label], clamp)."""
+    _req(logits, "logits")
+    _req(labels, "labels", torch.int64)
+    b, c, h, w = logits.shape
+    if labels.numel() != b * h * w:
+        raise RuntimeError("labels size mismatch")
+    probs = torch.empty_like(logits) if want_probs else None
+    acc = torch.zeros(1, dtype=torch.float64, device=logits.device)
+    check(_lib.load().slu_softmax_nll_fwd(logits.data_ptr(), labels.data_ptr(), b, c, h * w, float(clamp), _ptr(probs),
+                                          acc.data_ptr(), _stream()), "slu_softmax_nll_fwd")
+    return probs, acc

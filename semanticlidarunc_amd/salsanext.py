@@ -1,0 +1,234 @@
+"""SalsaNext on MI355X: the reference's module contract over hand-written HIP kernels.
+
+Contract mirrored from ``src/baselines/SalsaNext/SalsaNext.py:10-215`` of the reference
+(constructor ``SalsaNext(nclasses, nchannels=5)``, ``forward(x[B,nch,H,W]) -> logits[B,ncls,H,W]``,
+identical ``state_dict`` keys / OIHW fp32 shapes, genuine ``nn.Dropout2d`` children whose
+``.training`` flag is honoured per call so that ``utils.mc_dropout.set_dropout_mode`` works).
+
+What is different underneath: a block is not a chain of ATen ops but a handful of fused launches
+(``ops.conv2d_fused``): conv + bias + LeakyReLU + eval-BatchNorm + residual in one kernel,
+``torch.cat`` / ``PixelShuffle`` never materialised (the consumer conv reads its 2-3 sources
+directly) and every ``Dropout2d`` folded into a per-(sample, channel) multiplier that the consumer
+applies while staging its input tile.  The multipliers are drawn by the real ``nn.Dropout2d``
+children (on a ``[B,C,1,1]`` tensor of ones, i.e. the same Bernoulli noise shape ATen's feature
+dropout draws), so torch's RNG stream and the ``.training`` flags behave as in the reference.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ConvSource
+
+_SLOPE = 0.01  # nn.LeakyReLU() default used throughout the reference model
+
+
+class _Prepared:
+    """Device-side derived constants of one conv (+ its BatchNorm): the MFMA-ordered weight image and
+    the folded BN affine.  Rebuilt lazily whenever the owning parameters/buffers change."""
+
+    __slots__ = ("key", "wpack", "bn_key", "bn_a", "bn_b")
+
+    def __init__(self):
+        self.key = self.bn_key = None
+        self.wpack = self.bn_a = self.bn_b = None
+
+
+def _tkey(*ts):
+    return tuple((t.data_ptr(), t._version, t.device) for t in ts)
+
+
+class _FusedBlock(nn.Module):
+    """Shared machinery: run ``conv -> LeakyReLU -> BatchNorm(eval) [-> + resid]`` as one launch."""
+
+    def _run(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], srcs, resid=None, act=True):
+        cache: Dict[str, _Prepared] = self.__dict__.setdefault("_prep", {})
+        name = str(id(conv))
+        p = cache.get(name)
+        if p is None:
+            p = cache[name] = _Prepared()
+        wkey = _tkey(conv.weight)
+        if p.key != wkey:
+            p.wpack = ops.pack_conv_weight(conv.weight.detach().contiguous())
+            p.key = wkey
+        bn_a = bn_b = None
+        if bn is not None:
+            if bn.training:
+                raise NotImplementedError(
+                    "train-mode BatchNorm (batch statistics) is not available on the HIP path yet; "
+                    "call model.eval() (MC-dropout sampling keeps BatchNorm in eval mode anyway)")
+            bkey = _tkey(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            if p.bn_key != bkey:
+                p.bn_a, p.bn_b = ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+                p.bn_key = bkey
+            bn_a, bn_b = p.bn_a, p.bn_b
+        k = conv.kernel_size[0]
+        return ops.conv2d_fused(srcs, p.wpack, conv.out_channels, k, conv.dilation[0], conv.padding[0],
+                                bias=None if conv.bias is None else conv.bias.detach(),
+                                slope=_SLOPE if act else None, bn_a=bn_a, bn_b=bn_b, resid=resid)
+
+
+def _draw(drop: nn.Dropout2d, n: int, c: int, device, override: Optional[Dict[str, torch.Tensor]], name: str):
+    """[n,c] multiplier of one Dropout2d site, or None when it is the identity."""
+    if override is not None:
+        s = override.get(name)
+        return None if s is None else s.reshape(n, c).to(device=device, dtype=torch.float32).contiguous()
+    if not drop.training or drop.p == 0.0:
+        return None
+    return drop(torch.ones((n, c, 1, 1), dtype=torch.float32, device=device)).reshape(n, c)
+
+
+def _mul(a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    return a * b
+
+
+class ResContextBlock(_FusedBlock):
+    def __init__(self, in_filters, out_filters):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_filters, out_filters, 1)
+        self.conv2 = nn.Conv2d(out_filters, out_filters, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(out_filters)
+        self.conv3 = nn.Conv2d(out_filters, out_filters, 3, dilation=2, padding=2)
+        self.bn2 = nn.BatchNorm2d(out_filters)
+
+    def forward(self, x):
+        shortcut = self._run(self.conv1, None, [ConvSource(x)])
+        a1 = self._run(self.conv2, self.bn1, [ConvSource(shortcut)])
+        return self._run(self.conv3, self.bn2, [ConvSource(a1)], resid=shortcut)
+
+
+class ResBlock(_FusedBlock):
+    def __init__(self, in_filters, out_filters, dropout_rate, kernel_size=(3, 3), stride=1, pooling=True, drop_out=True):
+        super().__init__()
+        if stride != 1 or tuple(kernel_size) != (3, 3):
+            raise ValueError("only the stride-1 / 3x3-pool configuration of the reference is implemented")
+        self.pooling, self.drop_out = pooling, drop_out
+        self.conv1 = nn.Conv2d(in_filters, out_filters, 1)
+        self.conv2 = nn.Conv2d(in_filters, out_filters, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(out_filters)
+        self.conv3 = nn.Conv2d(out_filters, out_filters, 3, dilation=2, padding=2)
+        self.bn2 = nn.BatchNorm2d(out_filters)
+        self.conv4 = nn.Conv2d(out_filters, out_filters, 2, dilation=2, padding=1)
+        self.bn3 = nn.BatchNorm2d(out_filters)
+        self.conv5 = nn.Conv2d(out_filters * 3, out_filters, 1)
+        self.bn4 = nn.BatchNorm2d(out_filters)
+        self.dropout = nn.Dropout2d(p=dropout_rate)
+
+    def forward(self, x, _scales=None, _name=""):
+        """pooling: (pooled, full_res);  else: (full_res, deferred dropout multiplier or None)."""
+        src = [ConvSource(x)]
+        shortcut = self._run(self.conv1, None, src)
+        a1 = self._run(self.conv2, self.bn1, src)
+        a2 = self._run(self.conv3, self.bn2, [ConvSource(a1)])
+        a3 = self._run(self.conv4, self.bn3, [ConvSource(a2)])
+        full = self._run(self.conv5, self.bn4, [ConvSource(a1), ConvSource(a2), ConvSource(a3)], resid=shortcut)
+        s = None
+        if self.drop_out:
+            s = _draw(self.dropout, full.shape[0], full.shape[1], full.device, _scales, _name + ".dropout")
+        if self.pooling:
+            return ops.avgpool3s2(full, s), full
+        return full, s
+
+
+class UpBlock(_FusedBlock):
+    def __init__(self, in_filters, out_filters, dropout_rate, drop_out=True):
+        super().__init__()
+        self.drop_out, self.in_filters, self.out_filters = drop_out, in_filters, out_filters
+        self.dropout1 = nn.Dropout2d(p=dropout_rate)
+        self.dropout2 = nn.Dropout2d(p=dropout_rate)
+        self.conv1 = nn.Conv2d(in_filters // 4 + 2 * out_filters, out_filters, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(out_filters)
+        self.conv2 = nn.Conv2d(out_filters, out_filters, 3, dilation=2, padding=2)
+        self.bn2 = nn.BatchNorm2d(out_filters)
+        self.conv3 = nn.Conv2d(out_filters, out_filters, 2, dilation=2, padding=1)
+        self.bn3 = nn.BatchNorm2d(out_filters)
+        self.conv4 = nn.Conv2d(out_filters * 3, out_filters, 1)
+        self.bn4 = nn.BatchNorm2d(out_filters)
+        self.dropout3 = nn.Dropout2d(p=dropout_rate)
+
+    def forward(self, x, skip, x_scale=None, _scales=None, _name=""):
+        """x is read through PixelShuffle(2); x_scale is the producer's deferred dropout multiplier.
+        Returns (out, deferred multiplier of dropout3 or None)."""
+        n, cx, dev = x.shape[0], x.shape[1], x.device
+        cu, cs = cx // 4, skip.shape[1]
+        sx, ss = x_scale, None
+        if self.drop_out:
+            d1 = _draw(self.dropout1, n, cu, dev, _scales, _name + ".dropout1")
+            d2 = _draw(self.dropout2, n, cu + cs, dev, _scales, _name + ".dropout2")
+            up = d1
+            if d2 is not None:
+                up = _mul(up, d2[:, :cu])
+                ss = d2[:, cu:].contiguous()
+            if up is not None:      # shuffled channel c is fed by stored channels 4c..4c+3
+                sx = _mul(sx, up.repeat_interleave(4, dim=1))
+        if sx is not None:
+            sx = sx.contiguous()
+        e1 = self._run(self.conv1, self.bn1, [ConvSource(x, sx, True), ConvSource(skip, ss)])
+        e2 = self._run(self.conv2, self.bn2, [ConvSource(e1)])
+        e3 = self._run(self.conv3, self.bn3, [ConvSource(e2)])
+        out = self._run(self.conv4, self.bn4, [ConvSource(e1), ConvSource(e2), ConvSource(e3)])
+        s3 = None
+        if self.drop_out:
+            s3 = _draw(self.dropout3, n, out.shape[1], dev, _scales, _name + ".dropout3")
+        return out, s3
+
+
+class SalsaNext(_FusedBlock):
+    def __init__(self, nclasses, nchannels=5):
+        super().__init__()
+        self.nclasses = nclasses
+        self.downCntx = ResContextBlock(nchannels, 32)
+        self.downCntx2 = ResContextBlock(32, 32)
+        self.downCntx3 = ResContextBlock(32, 32)
+        self.resBlock1 = ResBlock(32, 64, 0.2, pooling=True, drop_out=False)
+        self.resBlock2 = ResBlock(64, 128, 0.2, pooling=True)
+        self.resBlock3 = ResBlock(128, 256, 0.2, pooling=True)
+        self.resBlock4 = ResBlock(256, 256, 0.2, pooling=True)
+        self.resBlock5 = ResBlock(256, 256, 0.2, pooling=False)
+        self.upBlock1 = UpBlock(256, 128, 0.2)
+        self.upBlock2 = UpBlock(128, 128, 0.2)
+        self.upBlock3 = UpBlock(128, 64, 0.2)
+        self.upBlock4 = UpBlock(64, 32, 0.2, drop_out=False)
+        self.logits = nn.Conv2d(32, nclasses, 1)
+        self.tail_act = nn.Softmax(dim=1)   # kept for module-tree parity; the reference forward never applies it
+
+    def forward(self, x):
+        """Raw logits [B, nclasses, H, W] (reference SalsaNext.py:197-215)."""
+        return self._forward(x, None)
+
+    def forward_with_dropout_scales(self, x, scales: Dict[str, torch.Tensor]):
+        """Same as forward() but with the Dropout2d multipliers given explicitly
+        (site name -> [B,C,1,1] or [B,C]; missing site = identity).  Used by the parity tests."""
+        return self._forward(x, scales)
+
+    def _forward(self, x, scales):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise RuntimeError("SalsaNext expects a [B, C, H, W] tensor")
+        if not x.is_cuda:
+            raise RuntimeError("semanticlidarunc_amd.SalsaNext runs on MI355X only: input is on "
+                               f"'{x.device}' and there is no CPU fallback")
+        if x.shape[2] % 16 or x.shape[3] % 16:
+            raise RuntimeError("SalsaNext needs H and W divisible by 16")
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("backward through the HIP path is not implemented yet; use torch.no_grad() / eval()")
+        x = x.contiguous().float()
+        d = self.downCntx(x)
+        d = self.downCntx2(d)
+        d = self.downCntx3(d)
+        d0c, d0b = self.resBlock1(d, scales, "resBlock1")
+        d1c, d1b = self.resBlock2(d0c, scales, "resBlock2")
+        d2c, d2b = self.resBlock3(d1c, scales, "resBlock3")
+        d3c, d3b = self.resBlock4(d2c, scales, "resBlock4")
+        d5c, s5 = self.resBlock5(d3c, scales, "resBlock5")
+        u4, s = self.upBlock1(d5c, d3b, s5, scales, "upBlock1")
+        u3, s = self.upBlock2(u4, d2b, s, scales, "upBlock2")
+        u2, s = self.upBlock3(u3, d1b, s, scales, "upBlock3")
+        u1, _ = self.upBlock4(u2, d0b, s, scales, "upBlock4")
+        return self._run(self.logits, None, [ConvSource(u1)], act=False)

@@ -1,0 +1,99 @@
+"""GPU: the drop-in SalsaNext module against the reference's logits (golden fixtures produced by
+the reference itself) and against the oracle at the BASELINE size.  Bar: <= 1e-3 abs (north star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import salsanext as osalsa
+from semanticlidarunc_amd.salsanext import SalsaNext
+from semanticlidarunc_amd.testing import seeded_model, synthetic_scan
+from semanticlidarunc_amd.utils.mc_dropout import mc_forward, set_dropout_mode
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def model(cuda):
+    return seeded_model(SalsaNext).to(cuda)
+
+
+def test_eval_forward_matches_reference_golden(cuda, model):
+    g = golden("salsanext_eval_1x5x16x64")
+    with torch.no_grad():
+        y = model(_t(g["x"]).to(cuda)).cpu()
+    err = float((y - _t(g["logits"])).abs().max())
+    assert y.shape == (1, 20, 16, 64) and err <= TOL, err
+
+
+def test_dropout_multipliers_match_reference_golden(cuda, model):
+    g = golden("salsanext_mc_2x5x32x64")
+    scales = {k[len("scale:"):]: _t(g[k]) for k in g.files if k.startswith("scale:")}
+    with torch.no_grad():
+        y = model.forward_with_dropout_scales(_t(g["x"]).to(cuda), scales).cpu()
+    err = float((y - _t(g["logits"])).abs().max())
+    assert err <= TOL, err
+
+
+def test_full_size_scan_matches_oracle(cuda, model):
+    # BASELINE config 1 shape: one 64x2048x5 scan, HIP vs the oracle (CPU, ~1 s)
+    x, _ = synthetic_scan(1, 64, 2048)
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = osalsa.salsanext_forward(sd, x)
+        got = model(x.to(cuda)).cpu()
+    err = float((got - want).abs().max())
+    assert err <= TOL, err
+    assert float((got.argmax(1) != want.argmax(1)).float().mean()) < 1e-3
+
+
+def test_batch_independence_and_determinism(cuda, model):
+    x, _ = synthetic_scan(3, 32, 128, seed=7)
+    x = x.to(cuda)
+    with torch.no_grad():
+        y = model(x)
+        y1 = model(x[1:2].contiguous())
+        y_again = model(x)
+    assert torch.equal(y, y_again)
+    assert float((y[1:2] - y1).abs().max()) <= 1e-5
+
+
+def test_mc_forward_draws_real_dropout_and_restores_modes(cuda, model):
+    x, _ = synthetic_scan(1, 32, 128, seed=8)
+    x = x.to(cuda)
+    torch.manual_seed(3)
+    out = mc_forward(model, [x], T=6)
+    assert out.shape == (6, 1, 20, 32, 128)
+    assert float(out.std(dim=0).mean()) > 1e-3             # passes differ
+    assert not any(m.training for m in model.modules())    # everything back in eval
+    with torch.no_grad():
+        e = model(x)
+    assert float((out.mean(0) - e).abs().mean()) < float(e.abs().mean())   # same scale as the eval output
+    # statistical parity of the folded masks: keep-rate of one site ~ 0.8, values in {0, 1.25}
+    set_dropout_mode(model, True)
+    from semanticlidarunc_amd.salsanext import _draw
+    s = _draw(model.resBlock3.dropout, 64, 256, cuda, None, "")
+    set_dropout_mode(model, False)
+    vals = torch.unique(s).cpu().tolist()
+    assert vals == [0.0, 1.25] and abs(float((s > 0).float().mean()) - 0.8) < 0.02
+
+
+def test_weight_update_invalidates_packed_cache(cuda):
+    m = seeded_model(SalsaNext).to(cuda)
+    x, _ = synthetic_scan(1, 16, 64, seed=9)
+    x = x.to(cuda)
+    with torch.no_grad():
+        y0 = m(x)
+        m.logits.weight.mul_(2.0)
+        m.logits.bias.mul_(2.0)
+        y1 = m(x)
+    assert float((y1 - 2.0 * y0).abs().max()) <= 1e-4
+    m.train()
+    with pytest.raises(NotImplementedError):
+        with torch.no_grad():
+            m(x)

@@ -1,0 +1,121 @@
+"""GPU: MC reduction / entropy maps / loss reduction / metric accumulators against the golden
+vectors and the oracle.  Floating point: 1e-5 abs (exp/log ulp differences); integers bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import losses as olosses, metrics as ometrics, uncertainty as ounc
+from semanticlidarunc_amd import ops
+from semanticlidarunc_amd.metrics.ece import ECEAggregator
+from semanticlidarunc_amd.models.evaluator import IoUEvaluator
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_mc_reduce_golden(cuda):
+    g = golden("mc_reduce_T4_1x20x4x64")
+    p_bar, h, mi, preds = ops.mc_reduce(_t(g["logits"]).to(cuda))
+    assert float((p_bar.cpu() - _t(g["p_bar"])).abs().max()) <= 1e-6
+    assert float((h.cpu() - _t(g["h_norm"])).abs().max()) <= 1e-5
+    assert float((mi.cpu() - _t(g["mi_norm"])).abs().max()) <= 1e-5
+    assert torch.equal(preds.cpu(), _t(g["preds"]))
+
+
+def test_mc_reduce_full_size_against_oracle_and_properties(cuda):
+    gen = torch.Generator().manual_seed(5)
+    lg = torch.randn(8, 1, 20, 64, 2048, generator=gen) * 2.5          # BASELINE shape, T=8
+    p_bar, h, mi, preds = ops.mc_reduce(lg.to(cuda))
+    wp, wh, wmi, wpr = ounc.mc_reduce(lg)
+    assert float((p_bar.cpu() - wp).abs().max()) <= 1e-6
+    assert float((h.cpu() - wh).abs().max()) <= 1e-5
+    assert float((mi.cpu() - wmi).abs().max()) <= 1e-5
+    assert float((preds.cpu() != wpr).float().mean()) < 1e-5            # argmax ties only
+    # size-independent properties
+    assert float((p_bar.sum(1) - 1).abs().max()) <= 1e-5
+    assert float(h.min()) >= 0 and float(h.max()) <= 1 + 1e-5 and float(mi.min()) >= 0
+    assert bool((mi <= h + 1e-5).all())
+    same = lg[:1].repeat(8, 1, 1, 1, 1).to(cuda)                         # identical passes -> MI = 0
+    _, _, mi0, _ = ops.mc_reduce(same)
+    assert float(mi0.max()) <= 1e-5
+
+
+def test_mc_reduce_other_class_counts_and_ragged(cuda):
+    gen = torch.Generator().manual_seed(6)
+    for t, b, c, hh, ww in [(3, 2, 3, 5, 7), (1, 1, 32, 3, 65), (5, 2, 21, 4, 64)]:
+        lg = torch.randn(t, b, c, hh, ww, generator=gen) * 3
+        got = ops.mc_reduce(lg.to(cuda))
+        want = ounc.mc_reduce(lg)
+        for a, w_ in zip(got[:3], want[:3]):
+            assert float((a.cpu() - w_).abs().max()) <= 1e-5
+        assert torch.equal(got[3].cpu(), want[3])
+    with pytest.raises(Exception):
+        ops.mc_reduce(torch.zeros(1, 1, 33, 2, 2, device=cuda))
+
+
+def test_single_pass_golden(cuda):
+    g = golden("single_pass_1x20x4x64")
+    probs, h, preds = ops.softmax_entropy(_t(g["logits"]).to(cuda))
+    assert float((probs.cpu() - _t(g["probs"])).abs().max()) <= 1e-6
+    assert float((h.cpu() - _t(g["h_norm"])).abs().max()) <= 1e-5
+    assert torch.equal(preds.cpu(), _t(g["preds"]))
+
+
+def test_softmax_nll_golden(cuda):
+    g = golden("loss_2x20x8x64")
+    lg, lab = _t(g["logits"]).to(cuda), _t(g["labels"]).to(cuda)
+    probs, acc = ops.softmax_nll(lg, lab)
+    nll = float(acc.item()) / lab.numel()
+    assert abs(nll - float(g["nll"])) <= 1e-5
+    assert float((probs.cpu() - torch.softmax(_t(g["logits"]), 1)).abs().max()) <= 1e-6
+    k = golden("kat_4px_2cls")      # probabilities given directly: feed log(p) as logits
+    _, acc = ops.softmax_nll(torch.log(_t(k["probs"])).to(cuda), _t(k["labels"]).to(cuda))
+    assert abs(float(acc.item()) / 4 - float(k["nll"])) <= 1e-5
+
+
+def test_confusion_matrix_bit_exact(cuda):
+    g = golden("iou_2x16x64")
+    ev = IoUEvaluator(20)
+    ev.update(_t(g["preds"]).to(cuda), _t(g["labels"]).to(cuda))
+    assert np.array_equal(ev.confmat.cpu().numpy(), g["confmat"])
+    miou, d = ev.compute([f"c{i}" for i in range(20)], test_mask=[0] + [1] * 19, ignore_gt=[0])
+    assert abs(miou - float(g["miou"])) < 1e-12
+    assert np.allclose([d[f"c{i}"] for i in range(20)], g["iou"], equal_nan=True)
+    # accumulation over updates, out-of-range values, BASELINE-size input
+    gen = torch.Generator().manual_seed(7)
+    p = torch.randint(-1, 22, (4, 64, 2048), generator=gen)
+    t = torch.randint(-1, 22, (4, 64, 2048), generator=gen)
+    ev.reset()
+    ev.update(p[:2].to(cuda), t[:2].to(cuda))
+    ev.update(p[2:].to(cuda), t[2:].to(cuda))
+    assert np.array_equal(ev.confmat.cpu().numpy(), ometrics.confusion_matrix(p.numpy(), t.numpy(), 20))
+
+
+def test_ece_bins_match_reference(cuda):
+    g = golden("ece_2x20x16x64")
+    agg = ECEAggregator(n_bins=15, mode="probs", ignore_index=0, max_samples=500000)
+    agg.update(_t(g["probs"]).to(cuda), _t(g["labels"]).to(cuda))
+    (e, m), stats, fig = agg.compute()
+    assert np.array_equal(stats["n"].to_numpy(), g["n"])                 # bin counts bit-exact
+    # reference sums its float32 weights with a float32 cumsum; the device sums in float64
+    assert abs(e - float(g["ece"])) <= 1e-5 and abs(m - float(g["mce"])) <= 1e-5
+    assert np.allclose(np.nan_to_num(stats["acc"].to_numpy()), g["acc"], atol=1e-5)
+    # edge cases: conf == 1.0 -> last bin; all ignored -> empty
+    p = torch.zeros(1, 20, 1, 64)
+    p[:, 3] = 1.0
+    lab = torch.full((1, 1, 64), 3, dtype=torch.int64)
+    agg.reset()
+    agg.update(p.to(cuda), lab.to(cuda))
+    (e, m), stats, _ = agg.compute()
+    assert stats["n"].to_numpy()[14] == 64 and e == 0.0
+    agg.reset()
+    agg.update(p.to(cuda), torch.zeros_like(lab).to(cuda))
+    assert np.isnan(agg.compute()[0][0])
+    # logits mode runs the device softmax first
+    agg2 = ECEAggregator(n_bins=15, mode="logits", ignore_index=0)
+    agg2.update(torch.log(_t(g["probs"])).to(cuda), _t(g["labels"]).to(cuda))
+    assert np.array_equal(agg2.compute()[1]["n"].to_numpy(), g["n"])
