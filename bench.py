@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scans", type=int, default=4, help="scans per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", default=None, help="write a per-kernel / per-layer-shape timing table to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,13 +114,22 @@ def main():
     (ece_v, _), _ = ece.compute()[:2]
 
     # ---- roofline of the dominant kernel: one extra step with HIP events around every conv launch ----
-    ops.TIMING = []
+    ops.TIMING, ops.TIMING_TAGS = [], []
     step()
     torch.cuda.synchronize()
     per_kernel = {}
     for name, flops, nbytes, e0, e1 in ops.TIMING:
         k = per_kernel.setdefault(name, [0, 0.0, 0.0, 0.0])
         k[0] += 1; k[1] += flops; k[2] += nbytes; k[3] += e0.elapsed_time(e1) * 1e-3
+    if args.breakdown and rank == 0:
+        with open(args.breakdown, "w") as f:
+            f.write("per kernel instantiation (one measured step)\n")
+            for name, k in sorted(per_kernel.items(), key=lambda kv: -kv[1][3]):
+                f.write(f"{k[3]*1e3:9.3f} ms  n={k[0]:3d}  {k[1]/k[3]/1e12:7.2f} TF/s  {k[2]/k[3]/1e9:8.1f} GB/s  {name}\n")
+            f.write("\nper launch, in launch order (name, ms, TFLOP/s, GB/s algorithmic, shape tag)\n")
+            for (name, flops, nbytes, e0, e1), tag in zip(ops.TIMING, ops.TIMING_TAGS):
+                ms = e0.elapsed_time(e1)
+                f.write(f"{ms:8.3f} ms {flops/ms/1e9:7.2f} TF/s {nbytes/ms/1e6:8.1f} GB/s  {tag}  {name}\n")
     ops.TIMING = None
     conv_s = sum(k[3] for k in per_kernel.values())
     conv_flops = sum(k[1] for k in per_kernel.values())

@@ -45,43 +45,78 @@ struct ConvArgs {
   float* out;
   float slope;
   int has_act;
+  int vec;  // W % 4 == 0 and every base pointer 16-byte aligned: float4 staging path
 };
 
-__device__ __forceinline__ float load_input(const ConvArgs& a, int n, int cg, int gy, int gx) {
+// Which source feeds conv-input channel cg (sources are channel-concatenated).
+struct SrcPick {
+  const float* ptr;
+  const float* scale;
+  int C, cl, ps;
+};
+__device__ __forceinline__ SrcPick pick_src(const ConvArgs& a, int cg) {
+  SrcPick p{a.src[0].ptr, a.src[0].scale, a.src[0].C, cg, a.src[0].ps};
 #pragma unroll
-  for (int s = 0; s < SLU_MAX_SRC; ++s) {
-    if (s < a.nsrc) {
-      const SrcDev& S = a.src[s];
-      const int cl = cg - S.cbeg;
-      if (cl >= 0 && cl < S.ccount) {
-        float v;
-        int cs;
-        if (!S.ps) {
-          cs = cl;
-          v = S.ptr[(((size_t)n * S.C + cs) * a.H + gy) * a.W + gx];
-        } else {
-          cs = cl * 4 + ((gy & 1) << 1) + (gx & 1);
-          v = S.ptr[(((size_t)n * S.C + cs) * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)];
-        }
-        if (S.scale) v *= S.scale[(size_t)n * S.C + cs];
-        return v;
-      }
-    }
+  for (int s = 1; s < SLU_MAX_SRC; ++s)
+    if (s < a.nsrc && cg >= a.src[s].cbeg) p = SrcPick{a.src[s].ptr, a.src[s].scale, a.src[s].C, cg - a.src[s].cbeg, a.src[s].ps};
+  return p;
+}
+
+// one element (any W): used only when W % 4 != 0
+__device__ __forceinline__ float load_input(const ConvArgs& a, int n, int cg, int gy, int gx) {
+  const SrcPick p = pick_src(a, cg);
+  float v;
+  int cs;
+  if (!p.ps) {
+    cs = p.cl;
+    v = p.ptr[(((size_t)n * p.C + cs) * a.H + gy) * a.W + gx];
+  } else {
+    cs = p.cl * 4 + ((gy & 1) << 1) + (gx & 1);
+    v = p.ptr[(((size_t)n * p.C + cs) * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)];
   }
-  return 0.0f;
+  if (p.scale) v *= p.scale[(size_t)n * p.C + cs];
+  return v;
+}
+
+// four azimuth-adjacent elements starting at gx4 (gx4 % 4 == 0, W % 4 == 0): one 16-byte load, or two
+// 8-byte loads interleaved when the source is read through PixelShuffle(2)
+__device__ __forceinline__ float4 load_input4(const ConvArgs& a, int n, int cg, int gy, int gx4) {
+  const SrcPick p = pick_src(a, cg);
+  if (!p.ps) {
+    float4 v = *reinterpret_cast<const float4*>(p.ptr + (((size_t)n * p.C + p.cl) * a.H + gy) * a.W + gx4);
+    if (p.scale) {
+      const float k = p.scale[(size_t)n * p.C + p.cl];
+      v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+    }
+    return v;
+  }
+  const int cs = p.cl * 4 + ((gy & 1) << 1);
+  const size_t hp = (size_t)(a.H >> 1) * (a.W >> 1);
+  const float* q = p.ptr + ((size_t)n * p.C + cs) * hp + (size_t)(gy >> 1) * (a.W >> 1) + (gx4 >> 1);
+  const float2 u = *reinterpret_cast<const float2*>(q);        // even output columns
+  const float2 w = *reinterpret_cast<const float2*>(q + hp);   // odd output columns (next stored channel)
+  float ku = 1.0f, kw = 1.0f;
+  if (p.scale) {
+    ku = p.scale[(size_t)n * p.C + cs];
+    kw = p.scale[(size_t)n * p.C + cs + 1];
+  }
+  return make_float4(u.x * ku, w.x * kw, u.y * ku, w.y * kw);
 }
 
 template <int KS, int DIL, int PAD, int CK, int MB, int WM, int WN, int RPW>
-__global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : 4) void conv_fwd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2) ? 3 : 4)) void conv_fwd_kernel(const ConvArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TW = 64, TH = WN * RPW, NB = 2 * RPW;
-  constexpr int LW = TW + 2 * PAD, LH = TH + 2 * PAD;
+  constexpr int XO = PAD ? 4 : 0;                 // the LDS tile starts XO (16-byte aligned) columns left of x0
+  constexpr int LW = TW + 2 * XO, LH = TH + 2 * PAD, LW4 = LW / 4;
   constexpr int PLANE = LH * LW;
   constexpr int HALF = CK / 2;
   constexpr int KSTEPS = KS * KS * HALF;
   constexpr int MBLK = WM * MB;
+  constexpr int NIV = CK * LH * LW4, NI = (NIV + NT - 1) / NT;              // float4 items of the input tile
+  constexpr int NWV = MBLK * KSTEPS * 16, NW = (NWV + NT - 1) / NT;          // float4 items of the weight tile
 
-  __shared__ float s_in[CK * PLANE];
+  __shared__ __attribute__((aligned(16))) float s_in[CK * PLANE];
   __shared__ __attribute__((aligned(16))) float s_w[MBLK * KSTEPS * 64];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -103,31 +138,65 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : 4) void conv_fw
       for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
 
   const int hh = lane >> 5, jj = lane & 31;
-  const int bbase = hh * PLANE + (wn * RPW) * LW + jj;
+  const int bbase = hh * PLANE + (wn * RPW) * LW + jj + (XO - PAD);
   const int abase = (wm * MB) * KSTEPS * 64 + lane;
 
   for (int q = 0; q < a.nchunks; ++q) {
     __syncthreads();
-    // ---- stage the halo tile of CK input channels (zero outside the image / beyond Cin) ----
-    for (int e = tid; e < CK * PLANE; e += NT) {
-      const int ci = e / PLANE;
-      const int rem = e - ci * PLANE;
-      const int r = rem / LW;
-      const int c = rem - r * LW;
-      const int gy = y0 + r - PAD, gx = x0 + c - PAD, cg = q * CK + ci;
-      float v = 0.0f;
-      if (cg < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = load_input(a, n, cg, gy, gx);
-      s_in[e] = v;
+    // keep the (chunk-invariant) staging address arithmetic from being hoisted out of this loop and
+    // held in registers across the MFMA phase: recompute it per chunk from an opaque copy of tid
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+    // ---- stage the halo tile of CK input channels (zero outside the image / beyond Cin).  All loads of
+    //      a thread are issued back to back (16 B each) before the first LDS write. ----
+    if (a.vec) {
+      float4 st[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int e = tq + i * NT;
+        const int ci = e / (LH * LW4);
+        const int rem = e - ci * (LH * LW4);
+        const int r = rem / LW4;
+        const int c4 = rem - r * LW4;
+        const int gy = y0 + r - PAD, gx4 = x0 - XO + 4 * c4, cg = q * CK + ci;
+        st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((NIV % NT == 0 || e < NIV) && cg < a.Cin && gy >= 0 && gy < a.H && gx4 >= 0 && gx4 < a.W)
+          st[i] = load_input4(a, n, cg, gy, gx4);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int e = tq + i * NT;
+        if (NIV % NT == 0 || e < NIV) reinterpret_cast<float4*>(s_in)[e] = st[i];
+      }
+    } else {
+      for (int e = tq; e < CK * PLANE; e += NT) {
+        const int ci = e / PLANE;
+        const int rem = e - ci * PLANE;
+        const int r = rem / LW;
+        const int c = rem - r * LW;
+        const int gy = y0 + r - PAD, gx = x0 + c - XO, cg = q * CK + ci;
+        float v = 0.0f;
+        if (cg < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = load_input(a, n, cg, gy, gx);
+        s_in[e] = v;
+      }
     }
     // ---- stage the A fragments of this chunk: MBLK contiguous runs of KSTEPS*64 floats ----
-    for (int e = tid; e < MBLK * KSTEPS * 16; e += NT) {
-      const int m = e / (KSTEPS * 16);
-      const int r = e - m * (KSTEPS * 16);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int mg = mblk0 + m;
-      if (mg < a.nmblk)
-        v = reinterpret_cast<const float4*>(a.wpack + ((size_t)mg * a.nchunks + q) * (KSTEPS * 64))[r];
-      reinterpret_cast<float4*>(s_w)[e] = v;
+    {
+      float4 sw[NW];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int e = tq + i * NT;
+        const int m = e / (KSTEPS * 16);
+        const int r = e - m * (KSTEPS * 16);
+        sw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((NWV % NT == 0 || e < NWV) && mblk0 + m < a.nmblk)
+          sw[i] = reinterpret_cast<const float4*>(a.wpack + ((size_t)(mblk0 + m) * a.nchunks + q) * (KSTEPS * 64))[r];
+      }
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int e = tq + i * NT;
+        if (NWV % NT == 0 || e < NWV) reinterpret_cast<float4*>(s_w)[e] = sw[i];
+      }
     }
     __syncthreads();
     // ---- K-steps ----
@@ -293,6 +362,9 @@ static int fill_args(const slu_conv_desc* d, ConvArgs& a) {
   a.nmblk = (d->Cout + 31) / 32;
   a.wpack = d->wpack; a.bias = d->bias; a.bn_a = d->bn_a; a.bn_b = d->bn_b; a.resid = d->resid; a.out = d->out;
   a.slope = d->slope; a.has_act = d->has_act;
+  a.vec = (d->W % 4 == 0);
+  for (int s = 0; s < d->nsrc; ++s)
+    if (reinterpret_cast<uintptr_t>(d->src[s].ptr) & 15) a.vec = 0;
   return SLU_OK;
 }
 

@@ -19,6 +19,7 @@ INT64_MIN = -(2 ** 63)
 # bench.py sets this to a list to collect (kernel name, algorithmic flops, algorithmic bytes, ev0, ev1)
 # per conv launch; None (the default) adds nothing to the launch path.
 TIMING = None
+TIMING_TAGS = []
 
 
 def _stream() -> int:
@@ -162,6 +163,7 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
     flops = 2.0 * cin * cout * ksize * ksize * n * h * w
     nbytes = 4.0 * (n * h * w * (cin + cout) + cout * cin * ksize * ksize)
     TIMING.append((buf.value.decode(), flops, nbytes, e0, e1))
+    TIMING_TAGS.append(f"N{n} {cin}->{cout} k{ksize}d{dil} {h}x{w}")
     return out
 
 
