@@ -47,7 +47,7 @@ const char* slu_strerror(int code);
  *
  * `in` is the channel concatenation of up to 3 sources; a source may be read through
  * PixelShuffle(2) and multiplied by a per-(n, source-channel) factor (folded Dropout2d).
- * Stride 1, "same" output size; kernel families (ksize,dil,pad) = (1,1,0) (3,1,1) (3,2,2) (2,2,1).
+ * `out` must not overlap any input (sources, resid).  Stride 1, "same" output size; kernel families (ksize,dil,pad) = (1,1,0) (3,1,1) (3,2,2) (2,2,1).
  * ------------------------------------------------------------------------------------------ */
 #define SLU_MAX_SRC 3
 
@@ -82,7 +82,7 @@ size_t slu_packed_weight_floats(int cout, int cin, int ksize, int ck);
 /* w: [cout, cin, ksize, ksize] (torch OIHW) -> out: packed image.  Re-run after every weight update. */
 int slu_pack_conv_weight(const float* w, int cout, int cin, int ksize, int ck, float* out, slu_stream_t stream);
 int slu_conv2d_fwd(const slu_conv_desc* desc, slu_stream_t stream);
-/* name of the kernel instantiation slu_conv2d_fwd launches for `desc` (as rocprofv3 prints it); HOST buf >= 48 bytes */
+/* name of the kernel instantiation slu_conv2d_fwd launches for `desc` (as rocprofv3 prints it); HOST buf >= 64 bytes */
 int slu_conv2d_kernel_name(const slu_conv_desc* desc, char* buf, size_t buflen);
 
 /* a = gamma / sqrt(var + eps), b = beta - mean * a   (eval-mode nn.BatchNorm2d, SalsaNext.py:32,36,...) */

@@ -46,6 +46,7 @@ struct ConvArgs {
   float slope;
   int has_act;
   int vec;  // W % 4 == 0 and every base pointer 16-byte aligned: float4 staging path
+  int gen;  // some source is read through PixelShuffle or carries a multiplier
 };
 
 // Which source feeds conv-input channel cg (sources are channel-concatenated).
@@ -78,33 +79,64 @@ __device__ __forceinline__ float load_input(const ConvArgs& a, int n, int cg, in
   return v;
 }
 
-// four azimuth-adjacent elements starting at gx4 (gx4 % 4 == 0, W % 4 == 0): one 16-byte load, or two
-// 8-byte loads interleaved when the source is read through PixelShuffle(2)
-__device__ __forceinline__ float4 load_input4(const ConvArgs& a, int n, int cg, int gy, int gx4) {
+// One float4 item of the input tile, held raw between its (unconditional, clamped-address) loads and the
+// LDS write so that no wait sits between the loads of different items.
+template <bool GEN>
+struct Item;
+template <>
+struct Item<false> {
+  float4 v;
+};
+template <>
+struct Item<true> {
+  float4 v;      // plain: 4 adjacent pixels; PixelShuffle: {even0, even1, odd0, odd1}
+  float ku, kw;  // folded-dropout multipliers (1 when the source has none)
+};
+
+// gx4 % 4 == 0, W % 4 == 0.  `ok` false -> address clamped to element 0 of the source (always mapped).
+template <bool GEN>
+__device__ __forceinline__ void fetch_item(const ConvArgs& a, int n, int cg, int gy, int gx4, bool ok, Item<GEN>& it, bool& is_ps) {
   const SrcPick p = pick_src(a, cg);
-  if (!p.ps) {
-    float4 v = *reinterpret_cast<const float4*>(p.ptr + (((size_t)n * p.C + p.cl) * a.H + gy) * a.W + gx4);
-    if (p.scale) {
-      const float k = p.scale[(size_t)n * p.C + p.cl];
-      v.x *= k; v.y *= k; v.z *= k; v.w *= k;
-    }
-    return v;
+  if constexpr (!GEN) {
+    const size_t idx = ok ? (((size_t)n * p.C + p.cl) * a.H + gy) * a.W + gx4 : 0;
+    it.v = *reinterpret_cast<const float4*>(p.ptr + idx);
+    is_ps = false;
+  } else {
+    const size_t hp = (size_t)(a.H >> 1) * (a.W >> 1);
+    const int cs = p.ps ? p.cl * 4 + ((gy & 1) << 1) : p.cl;
+    const size_t base = ((size_t)n * p.C + cs);
+    size_t i0 = p.ps ? base * hp + (size_t)(gy >> 1) * (a.W >> 1) + (gx4 >> 1) : (base * a.H + gy) * a.W + gx4;
+    size_t i1 = p.ps ? i0 + hp : i0 + 2;      // second 8-byte half: next stored channel / next two pixels
+    if (!ok) { i0 = 0; i1 = 0; }
+    const float2 u = *reinterpret_cast<const float2*>(p.ptr + i0);
+    const float2 w = *reinterpret_cast<const float2*>(p.ptr + i1);
+    it.v = make_float4(u.x, u.y, w.x, w.y);
+    const bool hs = ok && p.scale != nullptr;
+    const float* sp = hs ? p.scale + base : a.wpack;   // any mapped address when there is no multiplier
+    const float k0 = sp[0];
+    const float k1 = sp[(hs && p.ps) ? 1 : 0];
+    it.ku = hs ? k0 : 1.0f;
+    it.kw = hs ? k1 : 1.0f;
+    is_ps = p.ps != 0;
   }
-  const int cs = p.cl * 4 + ((gy & 1) << 1);
-  const size_t hp = (size_t)(a.H >> 1) * (a.W >> 1);
-  const float* q = p.ptr + ((size_t)n * p.C + cs) * hp + (size_t)(gy >> 1) * (a.W >> 1) + (gx4 >> 1);
-  const float2 u = *reinterpret_cast<const float2*>(q);        // even output columns
-  const float2 w = *reinterpret_cast<const float2*>(q + hp);   // odd output columns (next stored channel)
-  float ku = 1.0f, kw = 1.0f;
-  if (p.scale) {
-    ku = p.scale[(size_t)n * p.C + cs];
-    kw = p.scale[(size_t)n * p.C + cs + 1];
-  }
-  return make_float4(u.x * ku, w.x * kw, u.y * ku, w.y * kw);
 }
 
-template <int KS, int DIL, int PAD, int CK, int MB, int WM, int WN, int RPW>
-__global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2) ? 3 : 4)) void conv_fwd_kernel(const ConvArgs a) {
+template <bool GEN>
+__device__ __forceinline__ float4 item_value(const Item<GEN>& it, bool ok, bool is_ps) {
+  float4 r;
+  if constexpr (!GEN) {
+    r = it.v;
+  } else {
+    r = is_ps ? make_float4(it.v.x * it.ku, it.v.z * it.kw, it.v.y * it.ku, it.v.w * it.kw)
+              : make_float4(it.v.x * it.ku, it.v.y * it.ku, it.v.z * it.ku, it.v.w * it.ku);
+  }
+  return ok ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// GEN = false: plain sources (no PixelShuffle, no multipliers) -- every conv except UpBlock.conv1.
+// PF  = true : prefetch the next chunk's input tile into registers during the MFMA phase.
+template <int KS, int DIL, int PAD, int CK, int MB, int WM, int WN, int RPW, bool GEN>
+__global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2) ? 3 : 4)) void conv_fwd_kernel(const ConvArgs a, const float* __restrict__ resid, float* __restrict__ out) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TW = 64, TH = WN * RPW, NB = 2 * RPW;
   constexpr int XO = PAD ? 4 : 0;                 // the LDS tile starts XO (16-byte aligned) columns left of x0
@@ -118,10 +150,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
 
   __shared__ __attribute__((aligned(16))) float s_in[CK * PLANE];
   __shared__ __attribute__((aligned(16))) float s_w[MBLK * KSTEPS * 64];
+  __shared__ float s_epi[3 * MBLK * 32];          // bias | bn_a | bn_b of the workgroup's output channels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
+  // Workgroups are dealt round-robin over the 8 XCDs: give every XCD one contiguous run of tiles so that
+  // the halo rows/columns neighbouring tiles share are served by that XCD's own L2 (speed only).
   int t = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = t & 7, qq = nwg >> 3, rr = nwg & 7;
+    t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (t >> 3);
+  }
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;
@@ -137,6 +176,14 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
 
+  if (tid < MBLK * 32) {   // visible to everyone after the first barrier of the chunk loop
+    const int co = mblk0 * 32 + tid;
+    const bool ok = co < a.Cout;
+    s_epi[tid] = (ok && a.bias) ? a.bias[co] : 0.0f;
+    s_epi[MBLK * 32 + tid] = (ok && a.bn_a) ? a.bn_a[co] : 1.0f;
+    s_epi[2 * MBLK * 32 + tid] = (ok && a.bn_a) ? a.bn_b[co] : 0.0f;
+  }
+
   const int hh = lane >> 5, jj = lane & 31;
   const int bbase = hh * PLANE + (wn * RPW) * LW + jj + (XO - PAD);
   const int abase = (wm * MB) * KSTEPS * 64 + lane;
@@ -147,10 +194,23 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
     // held in registers across the MFMA phase: recompute it per chunk from an opaque copy of tid
     int tq = tid;
     asm volatile("" : "+v"(tq));
-    // ---- stage the halo tile of CK input channels (zero outside the image / beyond Cin).  All loads of
-    //      a thread are issued back to back (16 B each) before the first LDS write. ----
+    // ---- A fragments of this chunk (L2-resident, MBLK contiguous runs of KSTEPS*64 floats) ----
+    float4 sw[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int e = tq + i * NT;
+      int m = e / (KSTEPS * 16);
+      const int r = e - m * (KSTEPS * 16);
+      const bool ok = (NWV % NT == 0 || e < NWV) && mblk0 + m < a.nmblk;
+      const size_t off = ok ? ((size_t)(mblk0 + m) * a.nchunks + q) * (KSTEPS * 64) + 4 * r : 0;
+      sw[i] = *reinterpret_cast<const float4*>(a.wpack + off);
+      if (!ok) sw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- halo tile of CK input channels (zero outside the image / beyond Cin): all loads of a thread are
+    //      issued back to back (branch-free: clamped address + select), then written to LDS ----
     if (a.vec) {
-      float4 st[NI];
+      Item<GEN> st[NI];
+      unsigned okm = 0, psm = 0;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int e = tq + i * NT;
@@ -159,14 +219,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         const int r = rem / LW4;
         const int c4 = rem - r * LW4;
         const int gy = y0 + r - PAD, gx4 = x0 - XO + 4 * c4, cg = q * CK + ci;
-        st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((NIV % NT == 0 || e < NIV) && cg < a.Cin && gy >= 0 && gy < a.H && gx4 >= 0 && gx4 < a.W)
-          st[i] = load_input4(a, n, cg, gy, gx4);
+        const bool ok = (NIV % NT == 0 || e < NIV) && cg < a.Cin && gy >= 0 && gy < a.H && gx4 >= 0 && gx4 < a.W;
+        bool ps;
+        fetch_item<GEN>(a, n, ok ? cg : 0, gy, gx4, ok, st[i], ps);
+        okm |= (ok ? 1u : 0u) << i;
+        psm |= (ps ? 1u : 0u) << i;
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int e = tq + i * NT;
-        if (NIV % NT == 0 || e < NIV) reinterpret_cast<float4*>(s_in)[e] = st[i];
+        if (NIV % NT == 0 || e < NIV)
+          reinterpret_cast<float4*>(s_in)[e] = item_value<GEN>(st[i], (okm >> i) & 1u, (psm >> i) & 1u);
       }
     } else {
       for (int e = tq; e < CK * PLANE; e += NT) {
@@ -180,23 +243,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         s_in[e] = v;
       }
     }
-    // ---- stage the A fragments of this chunk: MBLK contiguous runs of KSTEPS*64 floats ----
-    {
-      float4 sw[NW];
 #pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const int e = tq + i * NT;
-        const int m = e / (KSTEPS * 16);
-        const int r = e - m * (KSTEPS * 16);
-        sw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((NWV % NT == 0 || e < NWV) && mblk0 + m < a.nmblk)
-          sw[i] = reinterpret_cast<const float4*>(a.wpack + ((size_t)(mblk0 + m) * a.nchunks + q) * (KSTEPS * 64))[r];
-      }
-#pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const int e = tq + i * NT;
-        if (NWV % NT == 0 || e < NWV) reinterpret_cast<float4*>(s_w)[e] = sw[i];
-      }
+    for (int i = 0; i < NW; ++i) {
+      const int e = tq + i * NT;
+      if (NWV % NT == 0 || e < NWV) reinterpret_cast<float4*>(s_w)[e] = sw[i];
     }
     __syncthreads();
     // ---- K-steps ----
@@ -217,30 +267,29 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
     }
   }
 
-  // ---- epilogue: bias, LeakyReLU, folded BatchNorm, residual, store (2 x 128 B per instruction) ----
+  // ---- epilogue: bias, LeakyReLU, folded BatchNorm, residual, store (2 x 128 B per instruction).
+  //      Per-channel constants come from LDS; `resid` / `out` are __restrict__ kernel arguments (the ABI
+  //      forbids out aliasing an input), so residual loads are scheduled ahead of the stores instead of
+  //      each waiting behind the previous store. ----
   const size_t plane = (size_t)a.H * a.W;
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
-    const int mg = mblk0 + wm * MB + i;
+    const int ml = wm * MB + i;               // channel block inside the workgroup tile
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = mg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (co >= a.Cout) continue;
-      const float bias = a.bias ? a.bias[co] : 0.0f;
-      const float ga = a.bn_a ? a.bn_a[co] : 1.0f;
-      const float gb = a.bn_a ? a.bn_b[co] : 0.0f;
-      const size_t cbase = ((size_t)n * a.Cout + co) * plane;
+    for (int b = 0; b < NB; ++b) {
+      const int gy = y0 + wn * RPW + (b >> 1), gx = x0 + (b & 1) * 32 + jj;
+      const bool pix_ok = gy < a.H && gx < a.W;
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int gy = y0 + wn * RPW + (b >> 1), gx = x0 + (b & 1) * 32 + jj;
-        if (gy < a.H && gx < a.W) {
-          float v = acc[i][b][r] + bias;
-          if (a.has_act) v = v > 0.0f ? v : v * a.slope;
-          if (a.bn_a) v = v * ga + gb;
-          const size_t o = cbase + (size_t)gy * a.W + gx;
-          if (a.resid) v += a.resid[o];
-          a.out[o] = v;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int co = mblk0 * 32 + cl;
+        const bool ok = pix_ok && co < a.Cout;
+        const size_t o = ok ? ((size_t)n * a.Cout + co) * plane + (size_t)gy * a.W + gx : 0;
+        float v = acc[i][b][r] + s_epi[cl];
+        if (a.has_act) v = v > 0.0f ? v : v * a.slope;
+        v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
+        if (resid) v += resid[o];
+        if (ok) out[o] = v;
       }
     }
   }
@@ -270,7 +319,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
 // ---------------------------------------------------------------------------------------------
 enum TileCfg { M32_TH8 = 0, M64_TH8, M128_TH4, M32_TH4, M64_TH4 };
 
-template <int KS, int DIL, int PAD, int CK, int MB, int WM, int WN, int RPW>
+template <int KS, int DIL, int PAD, int CK, int MB, int WM, int WN, int RPW, bool GEN>
 int launch_cfg(ConvArgs& a, hipStream_t st) {
   constexpr int TH = WN * RPW, MBLK = WM * MB;
   a.tiles_x = (a.W + 63) / 64;
@@ -278,21 +327,26 @@ int launch_cfg(ConvArgs& a, hipStream_t st) {
   const long long gx = (long long)a.tiles_x * a.tiles_y * a.N;
   const int gy = (a.nmblk + MBLK - 1) / MBLK;
   if (gx <= 0 || gx > 0x7fffffffLL || gy > 65535) return SLU_EUNSUPPORTED;
-  hipLaunchKernelGGL((conv_fwd_kernel<KS, DIL, PAD, CK, MB, WM, WN, RPW>), dim3((unsigned)gx, (unsigned)gy), dim3(64 * WM * WN),
-                     0, st, a);
+  hipLaunchKernelGGL((conv_fwd_kernel<KS, DIL, PAD, CK, MB, WM, WN, RPW, GEN>), dim3((unsigned)gx, (unsigned)gy), dim3(64 * WM * WN),
+                     0, st, a, a.resid, a.out);
   SLU_CHECK_LAUNCH();
+}
+
+template <int KS, int DIL, int PAD, int CK, bool GEN>
+int launch_tiles(ConvArgs& a, int cfg, hipStream_t st) {
+  switch (cfg) {
+    case M32_TH8:  return launch_cfg<KS, DIL, PAD, CK, 1, 1, 4, 2, GEN>(a, st);
+    case M64_TH8:  return launch_cfg<KS, DIL, PAD, CK, 2, 1, 4, 2, GEN>(a, st);
+    case M128_TH4: return launch_cfg<KS, DIL, PAD, CK, 2, 2, 2, 2, GEN>(a, st);
+    case M32_TH4:  return launch_cfg<KS, DIL, PAD, CK, 1, 1, 4, 1, GEN>(a, st);
+    case M64_TH4:  return launch_cfg<KS, DIL, PAD, CK, 2, 1, 4, 1, GEN>(a, st);
+  }
+  return SLU_EUNSUPPORTED;
 }
 
 template <int KS, int DIL, int PAD, int CK>
 int launch_family(ConvArgs& a, int cfg, hipStream_t st) {
-  switch (cfg) {
-    case M32_TH8:  return launch_cfg<KS, DIL, PAD, CK, 1, 1, 4, 2>(a, st);
-    case M64_TH8:  return launch_cfg<KS, DIL, PAD, CK, 2, 1, 4, 2>(a, st);
-    case M128_TH4: return launch_cfg<KS, DIL, PAD, CK, 2, 2, 2, 2>(a, st);
-    case M32_TH4:  return launch_cfg<KS, DIL, PAD, CK, 1, 1, 4, 1>(a, st);
-    case M64_TH4:  return launch_cfg<KS, DIL, PAD, CK, 2, 1, 4, 1>(a, st);
-  }
-  return SLU_EUNSUPPORTED;
+  return a.gen ? launch_tiles<KS, DIL, PAD, CK, true>(a, cfg, st) : launch_tiles<KS, DIL, PAD, CK, false>(a, cfg, st);
 }
 
 long long wg_count(const ConvArgs& a, int th, int mblk) {
@@ -363,8 +417,11 @@ static int fill_args(const slu_conv_desc* d, ConvArgs& a) {
   a.wpack = d->wpack; a.bias = d->bias; a.bn_a = d->bn_a; a.bn_b = d->bn_b; a.resid = d->resid; a.out = d->out;
   a.slope = d->slope; a.has_act = d->has_act;
   a.vec = (d->W % 4 == 0);
-  for (int s = 0; s < d->nsrc; ++s)
+  a.gen = 0;
+  for (int s = 0; s < d->nsrc; ++s) {
     if (reinterpret_cast<uintptr_t>(d->src[s].ptr) & 15) a.vec = 0;
+    if (d->src[s].pixel_shuffle || d->src[s].scale) a.gen = 1;
+  }
   return SLU_OK;
 }
 
@@ -384,12 +441,12 @@ extern "C" int slu_conv2d_fwd(const slu_conv_desc* d, slu_stream_t stream) {
 // Template arguments of the instantiation slu_conv2d_fwd would launch for this descriptor, in the
 // order rocprofv3 prints them: "conv_fwd_kernel<KS, DIL, PAD, CK, MB, WM, WN, RPW>".
 extern "C" int slu_conv2d_kernel_name(const slu_conv_desc* d, char* buf, size_t buflen) {
-  if (!buf || buflen < 48) return SLU_EINVAL;
+  if (!buf || buflen < 64) return SLU_EINVAL;
   ConvArgs a{};
   const int rc = fill_args(d, a);
   if (rc != SLU_OK) return rc;
   static const int kTile[5][4] = {{1, 1, 4, 2}, {2, 1, 4, 2}, {2, 2, 2, 2}, {1, 1, 4, 1}, {2, 1, 4, 1}};
   const int* t = kTile[choose_cfg(a)];
-  snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", d->ksize, d->dil, d->pad, d->ck, t[0], t[1], t[2], t[3]);
+  snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s>", d->ksize, d->dil, d->pad, d->ck, t[0], t[1], t[2], t[3], a.gen ? "true" : "false");
   return SLU_OK;
 }
