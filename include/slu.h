@@ -132,6 +132,37 @@ int slu_ece_update(const float* probs, const int64_t* labels, int B, int C, int 
 int slu_softmax_nll_fwd(const float* logits, const int64_t* labels, int B, int C, int HW, float clamp,
                         float* probs, double* nll_sum, slu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Per-pixel NLL / cross-entropy (models/losses.py:55-73, trainer.py:514).  x [B,C,HW]; pixels whose label is
+ * == ignore_index or outside [0,C) are skipped.  kind: 0 logits (nll = logsumexp - x_y, i.e. CrossEntropyLoss),
+ * 1 probs, -ln max(p_y, param);  2 probs, -ln(p_y + param);  3 log-probs, -x_y.
+ * fwd: nll_sum f64[1] += sum, count int64[1] += #pixels (caller zeroes both, divides).
+ * bwd: grad_x[B,C,HW] = gscale[0] * d(sum nll)/dx   (gscale: DEVICE scalar = upstream grad / count).
+ * ------------------------------------------------------------------------------------------ */
+int slu_nll_fwd(const float* x, const int64_t* labels, int B, int C, int HW, int kind, float param, int64_t ignore_index,
+                double* nll_sum, int64_t* count, slu_stream_t stream);
+int slu_nll_bwd(const float* x, const int64_t* labels, int B, int C, int HW, int kind, float param, int64_t ignore_index,
+                const float* gscale, float* grad_x, slu_stream_t stream);
+
+/* Softmax backward of the fused SalsaNext loss (trainer.py:511-516):
+ *   g_c = gout[0] * ( w_dense * dense[c]  -  [c == y and p_y >= clamp] * w_nll / p_y ),  grad_logits_c = p_c (g_c - sum_k g_k p_k)
+ * probs, dense (nullable), grad_logits [B,C,HW]; labels nullable; gout DEVICE scalar or NULL (= 1). */
+int slu_softmax_loss_bwd(const float* probs, const int64_t* labels, const float* dense, float w_dense, float w_nll, float clamp,
+                         const float* gout, int B, int C, int HW, float* grad_logits, slu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Lovasz-Softmax, classes='present' (losses/lovasz.py:12-88).  probs [B,C,HW] (rows sum to 1), labels int64 [B,HW];
+ * pixels with label == ignore_index are dropped (pass INT64_MIN for none).
+ *   loss[1]      : mean over present classes of  sum_k err_(k) * (J_k - J_{k-1})   (errors sorted descending)
+ *   n_present[1] : number of present classes (float)
+ *   grad_probs   : [B,C,HW] d loss / d probs, or NULL
+ * workspace: slu_lovasz_workspace_bytes(B,C,HW) bytes, 256-byte aligned, caller-owned scratch.
+ * ------------------------------------------------------------------------------------------ */
+size_t slu_lovasz_workspace_bytes(int B, int C, int HW);
+int slu_lovasz_fwd(const float* probs, const int64_t* labels, int B, int C, int HW, int64_t ignore_index,
+                   void* workspace, size_t workspace_bytes, float* loss, float* n_present, float* grad_probs,
+                   slu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,15 @@ SIGNATURES = {
                                  c_f64p, c_stream]),
     "slu_softmax_nll_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_f64p,
                                       c_stream]),
+    "slu_nll_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int64, c_f64p, c_i64p,
+                              c_stream]),
+    "slu_nll_bwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int64, c_f32p, c_f32p,
+                              c_stream]),
+    "slu_softmax_loss_bwd": (C.c_int, [c_f32p, c_i64p, c_f32p, C.c_float, C.c_float, C.c_float, c_f32p, C.c_int, C.c_int,
+                                       C.c_int, c_f32p, c_stream]),
+    "slu_lovasz_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "slu_lovasz_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_size_t, c_f32p,
+                                 c_f32p, c_f32p, c_stream]),
 }
 
 _lib = None

@@ -39,6 +39,13 @@ class CrossEntropyLoss(nn.Module):
         self.ignore_index = ignore_index
 
     def forward(self, outputs, labels, num_classes=20, model_act=None):
-        if model_act not in ("logits", "probs", "log_probs"):
+        if model_act == "logits":
+            kind, param = ops.NLL_LOGITS, 0.0
+        elif model_act == "probs":
+            kind, param = ops.NLL_PROBS_EPS, 1e-8       # NLL over log(p + 1e-8), as the reference
+        elif model_act == "log_probs":
+            kind, param = ops.NLL_LOG_PROBS, 0.0
+        else:
             raise ValueError(f"Unknown model_act: {model_act}")
-        raise NotImplementedError("CrossEntropyLoss on the HIP path lands with the backward kernels")
+        from semanticlidarunc_amd.loss import NllFn
+        return NllFn.apply(outputs, labels, kind, param, self.ignore_index)

@@ -255,3 +255,76 @@ def softmax_nll(logits: torch.Tensor, labels: torch.Tensor, clamp: float = 1e-8,
     check(_lib.load().slu_softmax_nll_fwd(logits.data_ptr(), labels.data_ptr(), b, c, h * w, float(clamp), _ptr(probs),
                                           acc.data_ptr(), _stream()), "slu_softmax_nll_fwd")
     return probs, acc
+
+
+# ------------------------------------------------------------------------------------------------
+# loss kernels
+# ------------------------------------------------------------------------------------------------
+NLL_LOGITS, NLL_PROBS_CLAMP, NLL_PROBS_EPS, NLL_LOG_PROBS = 0, 1, 2, 3
+
+
+def lovasz_fwd(probs: torch.Tensor, labels: torch.Tensor, ignore_index=None, want_grad: bool = True):
+    """(loss f32[1], n_present f32[1], grad_probs [B,C,H,W] or None) -- Lovasz-Softmax, classes='present'."""
+    _req(probs, "probs")
+    _req(labels, "labels", torch.int64)
+    b, c, h, w = probs.shape
+    if labels.numel() != b * h * w:
+        raise RuntimeError("labels size mismatch")
+    lib = _lib.load()
+    nbytes = lib.slu_lovasz_workspace_bytes(b, c, h * w)
+    if nbytes == 0:
+        raise RuntimeError("lovasz: unsupported shape")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=probs.device)
+    loss = torch.empty(1, dtype=torch.float32, device=probs.device)
+    npres = torch.empty(1, dtype=torch.float32, device=probs.device)
+    grad = torch.empty_like(probs) if want_grad else None
+    ign = INT64_MIN if ignore_index is None else int(ignore_index)
+    check(lib.slu_lovasz_fwd(probs.data_ptr(), labels.data_ptr(), b, c, h * w, ign, ws.data_ptr(), nbytes, loss.data_ptr(),
+                             npres.data_ptr(), _ptr(grad), _stream()), "slu_lovasz_fwd")
+    return loss, npres, grad
+
+
+def nll_fwd(x: torch.Tensor, labels: torch.Tensor, kind: int, param: float = 0.0, ignore_index=None):
+    """(nll_sum f64[1], count i64[1]) over pixels whose label is in [0,C) and != ignore_index."""
+    _req(x, "x")
+    _req(labels, "labels", torch.int64)
+    b, c, h, w = x.shape
+    if labels.numel() != b * h * w:
+        raise RuntimeError("labels size mismatch")
+    acc = torch.zeros(1, dtype=torch.float64, device=x.device)
+    cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
+    ign = INT64_MIN if ignore_index is None else int(ignore_index)
+    check(_lib.load().slu_nll_fwd(x.data_ptr(), labels.data_ptr(), b, c, h * w, int(kind), float(param), ign, acc.data_ptr(),
+                                  cnt.data_ptr(), _stream()), "slu_nll_fwd")
+    return acc, cnt
+
+
+def nll_bwd(x, labels, kind: int, param: float, ignore_index, gscale: torch.Tensor):
+    """grad_x = gscale[0] * d(sum nll)/dx ; gscale is a 1-element fp32 device tensor."""
+    _req(x, "x")
+    _req(labels, "labels", torch.int64)
+    _req(gscale, "gscale")
+    b, c, h, w = x.shape
+    g = torch.empty_like(x)
+    ign = INT64_MIN if ignore_index is None else int(ignore_index)
+    check(_lib.load().slu_nll_bwd(x.data_ptr(), labels.data_ptr(), b, c, h * w, int(kind), float(param), ign, gscale.data_ptr(),
+                                  g.data_ptr(), _stream()), "slu_nll_bwd")
+    return g
+
+
+def softmax_loss_bwd(probs, labels=None, dense=None, w_dense: float = 1.0, w_nll: float = 0.0, clamp: float = 0.0, gout=None):
+    """grad_logits = softmax backward of gout * (w_dense * dense - [c==y, p_y>=clamp] * w_nll / p_y)."""
+    _req(probs, "probs")
+    b, c, h, w = probs.shape
+    if labels is not None:
+        _req(labels, "labels", torch.int64)
+    if dense is not None:
+        _req(dense, "dense")
+        if dense.shape != probs.shape:
+            raise RuntimeError("dense gradient shape mismatch")
+    if gout is not None:
+        _req(gout, "gout")
+    g = torch.empty_like(probs)
+    check(_lib.load().slu_softmax_loss_bwd(probs.data_ptr(), _ptr(labels), _ptr(dense), float(w_dense), float(w_nll), float(clamp),
+                                           _ptr(gout), b, c, h * w, g.data_ptr(), _stream()), "slu_softmax_loss_bwd")
+    return g
