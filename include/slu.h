@@ -163,6 +163,39 @@ int slu_lovasz_fwd(const float* probs, const int64_t* labels, int B, int C, int 
                    void* workspace, size_t workspace_bytes, float* loss, float* n_present, float* grad_probs,
                    slu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training side of the conv stack (autograd of SalsaNext.py:25-39,73-109,142-170; nn.BatchNorm2d train mode).
+ * All tensors dense fp32; [N,C,HW] = NCHW with H*W flattened.  f64 accumulators are caller-zeroed, += semantics.
+ * ------------------------------------------------------------------------------------------ */
+/* sum[c] += sum y, sumsq[c] += sum y^2 over (N,HW) */
+int slu_bn_stats(const float* y, int N, int C, int HW, double* sum, double* sumsq, slu_stream_t stream);
+/* s1[c] += sum dz, s2[c] += sum dz * (y - mean[c]) * invstd[c] */
+int slu_bn_bwd_reduce(const float* dz, const float* y, const float* mean, const float* invstd, int N, int C, int HW,
+                      double* s1, double* s2, slu_stream_t stream);
+/* z = a[c]*y + b[c] + resid   (a, b, resid nullable: 1, 0, 0) */
+int slu_affine_fwd(const float* y, const float* a, const float* b, const float* resid, float* z, int N, int C, int HW,
+                   slu_stream_t stream);
+/* da = (k1[c]*dz + k2[c] + k3[c]*y) * (has_act && y <= 0 ? slope : 1);  dbias[c] += sum da  (k*, y, dbias nullable) */
+int slu_act_affine_bwd(const float* dz, const float* y, const float* k1, const float* k2, const float* k3, float slope,
+                       int has_act, int N, int C, int HW, float* da, double* dbias, slu_stream_t stream);
+/* src [N,C,HW] -> dst [N,HW,Cp], Cp = C rounded up to 32, padding channels zero */
+int slu_nchw_to_nhwc(const float* src, int N, int C, int HW, float* dst, slu_stream_t stream);
+/* the conv input described by `src` (concat / PixelShuffle / multipliers applied) as [N,H*W,Cp] */
+int slu_gather_nhwc(const slu_conv_src* src, int nsrc, int N, int H, int W, float* dst, slu_stream_t stream);
+/* gradient of one source: dsrc = (channels [cbeg, cbeg+contributed) of dcat [N,Ccat,H,W], un-shuffled) * scale[n,cs] */
+int slu_split_grad(const float* dcat, int N, int Ccat, int cbeg, int H, int W, int Csrc, int pixel_shuffle, const float* scale,
+                   float* dsrc, slu_stream_t stream);
+/* backward of slu_avgpool3s2_fwd: dy [N,C,(H+1)/2,(W+1)/2] -> dx [N,C,H,W] */
+int slu_avgpool3s2_bwd(const float* dy, const float* scale, float* dx, int N, int C, int H, int W, slu_stream_t stream);
+/* weights of the data-gradient conv: wd[ci][co][k-1-i][k-1-j] = w[co][ci][i][j]; feed to slu_pack_conv_weight and run
+ * slu_conv2d_fwd on da with Cin/Cout swapped (the four kernel families are symmetric: 2*pad == (k-1)*dil) */
+int slu_dgrad_weight(const float* w, int cout, int cin, int ksize, float* wd, slu_stream_t stream);
+/* dW [cout,cin,k,k] = sum_pixels da * shifted input; da_t [N,HW,Cop], in_t [N,HW,Cip] channel-last (padded to 32);
+ * dWp: scratch of slu_wgrad_packed_floats floats.  W must be even.  fp32 atomics: not bit-reproducible. */
+size_t slu_wgrad_packed_floats(int cout, int cin, int ksize);
+int slu_conv2d_wgrad(const float* da_t, const float* in_t, int N, int H, int W, int Cout, int Cin, int ksize, int dil, int pad,
+                     float* dWp, float* dW, slu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,11 +50,10 @@ class _Net:
         w, b = self.sd[name + ".weight"], self.sd[name + ".bias"]
         rm, rv = self.sd[name + ".running_mean"], self.sd[name + ".running_var"]
         if self.bn_train:
-            mean = x.mean(dim=(0, 2, 3))
-            var = x.var(dim=(0, 2, 3), unbiased=False)
-            self.bn_batch_stats[name] = (mean, var)
-            return (x - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + BN_EPS) \
-                * w[None, :, None, None] + b[None, :, None, None]
+            # batch statistics (biased variance), exactly nn.BatchNorm2d in train mode; the running-stat
+            # update (momentum 0.1, unbiased variance) is left to the caller via bn_batch_stats
+            self.bn_batch_stats[name] = (x.detach().mean(dim=(0, 2, 3)), x.detach().var(dim=(0, 2, 3), unbiased=False))
+            return F.batch_norm(x, None, None, w, b, True, 0.0, BN_EPS)
         return F.batch_norm(x, rm, rv, w, b, False, 0.0, BN_EPS)
 
     def cab(self, x, conv, bn, pad=0, dil=1):

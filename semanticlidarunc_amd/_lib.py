@@ -65,6 +65,20 @@ SIGNATURES = {
                               c_stream]),
     "slu_softmax_loss_bwd": (C.c_int, [c_f32p, c_i64p, c_f32p, C.c_float, C.c_float, C.c_float, c_f32p, C.c_int, C.c_int,
                                        C.c_int, c_f32p, c_stream]),
+    "slu_bn_stats": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, c_stream]),
+    "slu_bn_bwd_reduce": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, c_stream]),
+    "slu_affine_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_act_affine_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     c_f32p, c_f64p, c_stream]),
+    "slu_nchw_to_nhwc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "slu_gather_nhwc": (C.c_int, [C.POINTER(ConvSrc), C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "slu_split_grad": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
+                                 c_stream]),
+    "slu_avgpool3s2_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_dgrad_weight": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "slu_wgrad_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "slu_conv2d_wgrad": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   c_f32p, c_f32p, c_stream]),
     "slu_lovasz_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_lovasz_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_size_t, c_f32p,
                                  c_f32p, c_f32p, c_stream]),

@@ -1,0 +1,133 @@
+"""`torch.autograd.Function`s for the conv stack: one node per fused layer
+(cat / PixelShuffle / Dropout2d multipliers -> Conv2d -> LeakyReLU -> BatchNorm -> + residual) and one for the pool.
+
+Used whenever gradients are required or BatchNorm is in train mode; pure inference takes the single fused
+kernel instead (`salsanext._FusedBlock._run`).  Backward reads only saved tensors, so it is re-entrant
+(`torch.autograd.grad(..., retain_graph=True)` as in the reference's utils/grad_norm.py:52).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ConvSource
+
+
+class LayerCfg:
+    """Non-tensor description of one fused layer call (plain Python, ignored by autograd)."""
+    __slots__ = ("ksize", "dil", "pad", "slope", "scales", "shuffles", "bn", "cout", "wpack", "wdpack_cache")
+
+    def __init__(self, ksize, dil, pad, slope, scales, shuffles, bn, cout, wpack, wdpack_cache):
+        self.ksize, self.dil, self.pad, self.slope = ksize, dil, pad, slope
+        self.scales, self.shuffles, self.bn, self.cout = scales, shuffles, bn, cout
+        self.wpack, self.wdpack_cache = wpack, wdpack_cache
+
+
+class ConvLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg: LayerCfg, weight, bias, gamma, beta, resid, *tensors):
+        srcs = [ConvSource(t.detach().contiguous(), s, ps) for t, s, ps in zip(tensors, cfg.scales, cfg.shuffles)]
+        y = ops.conv2d_fused(srcs, cfg.wpack, cfg.cout, cfg.ksize, cfg.dil, cfg.pad,
+                             bias=None if bias is None else bias.detach(), slope=cfg.slope)
+        bn: Optional[nn.BatchNorm2d] = cfg.bn
+        mean = invstd = None
+        train_stats = False
+        if bn is not None:
+            n, c, h, w = y.shape
+            m = n * h * w
+            if bn.training:
+                train_stats = True
+                s, q = ops.bn_stats(y)
+                mean64 = s / m
+                var64 = (q / m - mean64 * mean64).clamp_min(0.0)
+                with torch.no_grad():
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    if bn.track_running_stats and bn.running_mean is not None:
+                        bn.running_mean.mul_(1.0 - mom).add_(mean64.float(), alpha=mom)
+                        bn.running_var.mul_(1.0 - mom).add_((var64 * (m / max(1, m - 1))).float(), alpha=mom)
+                        bn.num_batches_tracked += 1
+            else:
+                mean64, var64 = bn.running_mean.double(), bn.running_var.double()
+            invstd64 = torch.rsqrt(var64 + bn.eps)
+            a = (gamma.detach().double() * invstd64).float()
+            b = (beta.detach().double() - mean64 * gamma.detach().double() * invstd64).float()
+            mean, invstd = mean64.float(), invstd64.float()
+            z = ops.affine(y, a, b, None if resid is None else resid.detach().contiguous())
+        elif resid is not None:
+            z = ops.affine(y, None, None, resid.detach().contiguous())
+        else:
+            z = y
+        ctx.cfg, ctx.train_stats, ctx.has_bn, ctx.has_resid = cfg, train_stats, bn is not None, resid is not None
+        ctx.src_shapes = [tuple(t.shape) for t in tensors]
+        ctx.has_bias = bias is not None
+        saved = [weight, y] + [t.detach() for t in tensors]
+        if bn is not None:
+            saved += [gamma, mean, invstd]
+        ctx.save_for_backward(*saved)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        cfg: LayerCfg = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        weight, y = saved[0], saved[1]
+        nsrc = len(ctx.src_shapes)
+        tensors = saved[2:2 + nsrc]
+        dz = dz.contiguous().float()
+        n, c, h, w = y.shape
+        need = ctx.needs_input_grad                      # (cfg, weight, bias, gamma, beta, resid, *tensors)
+        d_resid = dz if (ctx.has_resid and need[5]) else None
+        dgamma = dbeta = None
+        k1 = k2 = k3 = None
+        if ctx.has_bn:
+            gamma, mean, invstd = saved[2 + nsrc:5 + nsrc]
+            s1, s2 = ops.bn_bwd_reduce(dz, y, mean, invstd)
+            dgamma, dbeta = s2.float(), s1.float()
+            g64, is64 = gamma.detach().double(), invstd.double()
+            k1 = (g64 * is64).float()
+            if ctx.train_stats:
+                m = float(n * h * w)
+                k3_64 = -g64 * is64 * is64 * s2 / m
+                k2 = (-g64 * is64 * s1 / m - k3_64 * mean.double()).float()
+                k3 = k3_64.float()
+        da, db = ops.act_affine_bwd(dz, y if (cfg.slope is not None or k3 is not None) else None, k1, k2, k3, cfg.slope, ctx.has_bias)
+        dbias = db.float() if (ctx.has_bias and need[2]) else None
+        srcs = [ConvSource(t.contiguous(), s, ps) for t, s, ps in zip(tensors, cfg.scales, cfg.shuffles)]
+        cin = weight.shape[1]
+        dweight = None
+        if need[1]:
+            dweight = ops.conv2d_wgrad(ops.nchw_to_nhwc(da), ops.gather_nhwc(srcs), n, h, w, cfg.cout, cin, cfg.ksize, cfg.dil, cfg.pad)
+        dsrc: List[Optional[torch.Tensor]] = [None] * nsrc
+        if any(need[6:6 + nsrc]):
+            key = (weight.data_ptr(), weight._version)
+            if cfg.wdpack_cache.get("key") != key:
+                cfg.wdpack_cache["pack"] = ops.pack_conv_weight(ops.dgrad_weight(weight.detach().contiguous()))
+                cfg.wdpack_cache["key"] = key
+            dcat = ops.conv2d_fused([ConvSource(da)], cfg.wdpack_cache["pack"], cin, cfg.ksize, cfg.dil, cfg.pad)
+            cbeg = 0
+            for i, (shape, s, ps) in enumerate(zip(ctx.src_shapes, cfg.scales, cfg.shuffles)):
+                contributed = shape[1] // 4 if ps else shape[1]
+                if need[6 + i]:
+                    if nsrc == 1 and not ps and s is None:
+                        dsrc[i] = dcat
+                    else:
+                        dsrc[i] = ops.split_grad(dcat, cbeg, shape, ps, s)
+                cbeg += contributed
+        return (None, dweight, dbias, dgamma if need[3] else None, dbeta if need[4] else None, d_resid, *dsrc)
+
+
+class AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.shape = tuple(x.shape)
+        ctx.save_for_backward(scale if scale is not None else torch.empty(0, device=x.device))
+        ctx.has_scale = scale is not None
+        return ops.avgpool3s2(x.detach().contiguous(), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        return ops.avgpool3s2_bwd(dy.contiguous().float(), scale if ctx.has_scale else None, ctx.shape), None

@@ -1,0 +1,271 @@
+// Training-side per-pixel kernels around the conv stack (HBM-bound):
+//   train-mode BatchNorm statistics / apply, BatchNorm + LeakyReLU backward, per-channel reductions,
+//   NCHW -> NHWC transposes (the weight-gradient kernel wants channels on the lanes), gradient split of a
+//   concatenated / pixel-shuffled / dropout-scaled conv input, average-pool backward.
+// Reference semantics: nn.BatchNorm2d (biased batch variance for normalisation, SalsaNext.py:32,...),
+// nn.LeakyReLU(0.01), nn.AvgPool2d(3,2,1), nn.PixelShuffle(2), nn.Dropout2d as a per-(n,c) multiplier.
+#include "slu_common.h"
+
+namespace {
+
+// ---- per-channel reductions over (N, HW): 2-D grid (chunk of pixels, channel) ----------------------
+// mode 0: sum y, sum y^2            (batch statistics)
+// mode 1: sum g, sum g * (y - mean[c]) * invstd[c]   (BatchNorm backward)
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ p, const float* __restrict__ q,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          int N, int C, int HW, double* __restrict__ o1, double* __restrict__ o2) {
+  const int c = blockIdx.y;
+  const size_t per_c = (size_t)N * HW;
+  double a1 = 0.0, a2 = 0.0;
+  const float mu = MODE == 1 ? mean[c] : 0.0f, is = MODE == 1 ? invstd[c] : 0.0f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_c; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, hw = i - n * HW;
+    const size_t idx = (n * C + c) * HW + hw;
+    if (MODE == 0) {
+      const float v = p[idx];
+      a1 += (double)v;
+      a2 += (double)v * (double)v;
+    } else {
+      const float g = p[idx];
+      a1 += (double)g;
+      a2 += (double)(g * ((q[idx] - mu) * is));
+    }
+  }
+  __shared__ double s1[4], s2[4];
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = a1; s2[threadIdx.x >> 6] = a2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&o1[c], s1[0] + s1[1] + s1[2] + s1[3]);
+    atomicAdd(&o2[c], s2[0] + s2[1] + s2[2] + s2[3]);
+  }
+}
+
+// z = a[c] * y + b[c] (+ resid)
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ y, const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ resid, float* __restrict__ z, int C, int HW, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((e / HW) % C);
+    float v = y[e] * (a ? a[c] : 1.0f) + (b ? b[c] : 0.0f);
+    if (resid) v += resid[e];
+    z[e] = v;
+  }
+}
+
+// da = (k1[c] * dz + k2[c] + k3[c] * y) * leaky'(y)      and      dbias[c] += sum da
+__global__ __launch_bounds__(256) void act_affine_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                             const float* __restrict__ k1, const float* __restrict__ k2,
+                                                             const float* __restrict__ k3, float slope, int has_act, int N, int C,
+                                                             int HW, float* __restrict__ da, double* __restrict__ dbias) {
+  const int c = blockIdx.y;
+  const size_t per_c = (size_t)N * HW;
+  const float c1 = k1 ? k1[c] : 1.0f, c2 = k2 ? k2[c] : 0.0f, c3 = k3 ? k3[c] : 0.0f;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_c; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, hw = i - n * HW;
+    const size_t idx = (n * C + c) * HW + hw;
+    const float yv = y ? y[idx] : 0.0f;
+    float g = c1 * dz[idx] + c2 + c3 * yv;
+    if (has_act && !(yv > 0.0f)) g *= slope;
+    da[idx] = g;
+    acc += (double)g;
+  }
+  if (dbias) {
+    __shared__ double s[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&dbias[c], s[0] + s[1] + s[2] + s[3]);
+  }
+}
+
+// ---- [N,C,HW] -> [N,HW,Cp] (Cp = C rounded up to 32, zero filled) through a 32x64 LDS tile ----------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, int C, int Cp, int HW, float* __restrict__ dst) {
+  __shared__ float tile[32][65];
+  const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int c = c0 + ty + 4 * r, p = p0 + tx;
+    tile[ty + 4 * r][tx] = (c < C && p < HW) ? src[((size_t)n * C + c) * HW + p] : 0.0f;
+  }
+  __syncthreads();
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;       // 32 x 8
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int p = p0 + py + 8 * r;
+    if (p < HW) dst[((size_t)n * HW + p) * Cp + c0 + cx] = tile[cx][py + 8 * r];
+  }
+}
+
+struct GatherArgs {
+  const float* ptr[SLU_MAX_SRC];
+  const float* scale[SLU_MAX_SRC];
+  int C[SLU_MAX_SRC], ps[SLU_MAX_SRC], cbeg[SLU_MAX_SRC], ccount[SLU_MAX_SRC];
+  int nsrc, H, W, Cin, Cp;
+};
+
+// the conv's actual input (concat of sources, PixelShuffle, multipliers) as [N,H*W,Cp]
+__global__ __launch_bounds__(256) void gather_nhwc_kernel(const GatherArgs a, float* __restrict__ dst) {
+  __shared__ float tile[32][65];
+  const int HW = a.H * a.W;
+  const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int cg = c0 + ty + 4 * r, p = p0 + tx;
+    float v = 0.0f;
+    if (cg < a.Cin && p < HW) {
+      const int gy = p / a.W, gx = p - gy * a.W;
+#pragma unroll
+      for (int s = 0; s < SLU_MAX_SRC; ++s) {
+        const int cl = cg - a.cbeg[s];
+        if (s < a.nsrc && cl >= 0 && cl < a.ccount[s]) {
+          int cs;
+          if (!a.ps[s]) {
+            cs = cl;
+            v = a.ptr[s][(((size_t)n * a.C[s] + cs) * a.H + gy) * a.W + gx];
+          } else {
+            cs = cl * 4 + ((gy & 1) << 1) + (gx & 1);
+            v = a.ptr[s][(((size_t)n * a.C[s] + cs) * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)];
+          }
+          if (a.scale[s]) v *= a.scale[s][(size_t)n * a.C[s] + cs];
+        }
+      }
+    }
+    tile[ty + 4 * r][tx] = v;
+  }
+  __syncthreads();
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int p = p0 + py + 8 * r;
+    if (p < HW) dst[((size_t)n * HW + p) * a.Cp + c0 + cx] = tile[cx][py + 8 * r];
+  }
+}
+
+// gradient of one source of a conv input: dsrc[n,cs,..] = dcat[n, cbeg + f(cs), ..] * scale[n,cs]
+__global__ __launch_bounds__(256) void split_grad_kernel(const float* __restrict__ dcat, int Ccat, int cbeg, int H, int W, int Csrc, int ps,
+                                                         const float* __restrict__ scale, float* __restrict__ dsrc, size_t total) {
+  const int h = ps ? H >> 1 : H, w = ps ? W >> 1 : W;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(e % w);
+    size_t r = e / w;
+    const int y = (int)(r % h);
+    r /= h;
+    const int cs = (int)(r % Csrc);
+    const size_t n = r / Csrc;
+    int c, gy, gx;
+    if (ps) { c = cs >> 2; gy = 2 * y + ((cs >> 1) & 1); gx = 2 * x + (cs & 1); }
+    else    { c = cs; gy = y; gx = x; }
+    float v = dcat[((n * Ccat + cbeg + c) * H + gy) * W + gx];
+    if (scale) v *= scale[n * Csrc + cs];
+    dsrc[e] = v;
+  }
+}
+
+// dx of y = avgpool3s2(x * s): dx[n,c,iy,ix] = s/9 * sum of dy over the (<= 2x2) windows covering (iy,ix)
+__global__ __launch_bounds__(256) void avgpool3s2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ scale,
+                                                             float* __restrict__ dx, int NC, int H, int W, int OH, int OW) {
+  const size_t total = (size_t)NC * H * W;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ix = (int)(e % W);
+    const size_t r = e / W;
+    const int iy = (int)(r % H);
+    const size_t nc = r / H;
+    const float* p = dy + nc * (size_t)OH * OW;
+    float acc = 0.0f;
+    const int oy0 = iy >> 1, ox0 = ix >> 1;
+    const int ny = (iy & 1) ? 2 : 1, nx = (ix & 1) ? 2 : 1;
+    for (int i = 0; i < ny; ++i) {
+      const int oy = oy0 + i;
+      if (oy >= OH) continue;
+      for (int j = 0; j < nx; ++j) {
+        const int ox = ox0 + j;
+        if (ox < OW) acc += p[(size_t)oy * OW + ox];
+      }
+    }
+    dx[e] = acc / 9.0f * (scale ? scale[nc] : 1.0f);
+  }
+}
+
+inline unsigned cap(size_t n, unsigned c) { return (unsigned)(n > c ? c : (n ? n : 1)); }
+
+}  // namespace
+
+extern "C" int slu_bn_stats(const float* y, int N, int C, int HW, double* sum, double* sumsq, slu_stream_t stream) {
+  if (!y || !sum || !sumsq || N <= 0 || C <= 0 || HW <= 0 || C > 65535) return SLU_EINVAL;
+  const unsigned gx = cap(((size_t)N * HW + 2047) / 2048, 256);
+  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(gx, C), dim3(256), 0, slu_stream(stream), y, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, N, C, HW, sum, sumsq);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_bn_bwd_reduce(const float* dz, const float* y, const float* mean, const float* invstd, int N, int C, int HW,
+                                 double* s1, double* s2, slu_stream_t stream) {
+  if (!dz || !y || !mean || !invstd || !s1 || !s2 || N <= 0 || C <= 0 || HW <= 0 || C > 65535) return SLU_EINVAL;
+  const unsigned gx = cap(((size_t)N * HW + 2047) / 2048, 256);
+  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(gx, C), dim3(256), 0, slu_stream(stream), dz, y, mean, invstd, N, C, HW, s1, s2);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_affine_fwd(const float* y, const float* a, const float* b, const float* resid, float* z, int N, int C, int HW,
+                              slu_stream_t stream) {
+  if (!y || !z || N <= 0 || C <= 0 || HW <= 0) return SLU_EINVAL;
+  const size_t total = (size_t)N * C * HW;
+  hipLaunchKernelGGL(affine_kernel, dim3(cap((total + 255) / 256, 16384)), dim3(256), 0, slu_stream(stream), y, a, b, resid, z, C, HW, total);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_act_affine_bwd(const float* dz, const float* y, const float* k1, const float* k2, const float* k3, float slope,
+                                  int has_act, int N, int C, int HW, float* da, double* dbias, slu_stream_t stream) {
+  if (!dz || !da || N <= 0 || C <= 0 || HW <= 0 || C > 65535) return SLU_EINVAL;
+  if ((has_act || k3) && !y) return SLU_EINVAL;
+  const unsigned gx = cap(((size_t)N * HW + 2047) / 2048, 256);
+  hipLaunchKernelGGL(act_affine_bwd_kernel, dim3(gx, C), dim3(256), 0, slu_stream(stream), dz, y, k1, k2, k3, slope, has_act, N, C, HW, da, dbias);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_nchw_to_nhwc(const float* src, int N, int C, int HW, float* dst, slu_stream_t stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || HW <= 0 || N > 65535) return SLU_EINVAL;
+  const int Cp = (C + 31) / 32 * 32;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 63) / 64, Cp / 32, N), dim3(256), 0, slu_stream(stream), src, C, Cp, HW, dst);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_gather_nhwc(const slu_conv_src* src, int nsrc, int N, int H, int W, float* dst, slu_stream_t stream) {
+  if (!src || !dst || nsrc < 1 || nsrc > SLU_MAX_SRC || N <= 0 || H <= 0 || W <= 0 || N > 65535) return SLU_EINVAL;
+  GatherArgs a{};
+  int c = 0;
+  for (int s = 0; s < nsrc; ++s) {
+    if (!src[s].ptr || src[s].C <= 0) return SLU_EINVAL;
+    if (src[s].pixel_shuffle && ((src[s].C & 3) || (H & 1) || (W & 1))) return SLU_EINVAL;
+    a.ptr[s] = src[s].ptr; a.scale[s] = src[s].scale; a.C[s] = src[s].C; a.ps[s] = src[s].pixel_shuffle ? 1 : 0;
+    a.cbeg[s] = c; a.ccount[s] = src[s].pixel_shuffle ? src[s].C / 4 : src[s].C;
+    c += a.ccount[s];
+  }
+  a.nsrc = nsrc; a.H = H; a.W = W; a.Cin = c; a.Cp = (c + 31) / 32 * 32;
+  hipLaunchKernelGGL(gather_nhwc_kernel, dim3((H * W + 63) / 64, a.Cp / 32, N), dim3(256), 0, slu_stream(stream), a, dst);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_split_grad(const float* dcat, int N, int Ccat, int cbeg, int H, int W, int Csrc, int pixel_shuffle, const float* scale,
+                              float* dsrc, slu_stream_t stream) {
+  if (!dcat || !dsrc || N <= 0 || Ccat <= 0 || Csrc <= 0 || H <= 0 || W <= 0 || cbeg < 0) return SLU_EINVAL;
+  const int contributed = pixel_shuffle ? Csrc / 4 : Csrc;
+  if (cbeg + contributed > Ccat || (pixel_shuffle && ((Csrc & 3) || (H & 1) || (W & 1)))) return SLU_EINVAL;
+  const size_t total = (size_t)N * Csrc * (pixel_shuffle ? (H >> 1) * (size_t)(W >> 1) : (size_t)H * W);
+  hipLaunchKernelGGL(split_grad_kernel, dim3(cap((total + 255) / 256, 16384)), dim3(256), 0, slu_stream(stream), dcat, Ccat, cbeg, H, W, Csrc,
+                     pixel_shuffle ? 1 : 0, scale, dsrc, total);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_avgpool3s2_bwd(const float* dy, const float* scale, float* dx, int N, int C, int H, int W, slu_stream_t stream) {
+  if (!dy || !dx || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SLU_EINVAL;
+  const size_t total = (size_t)N * C * H * W;
+  hipLaunchKernelGGL(avgpool3s2_bwd_kernel, dim3(cap((total + 255) / 256, 16384)), dim3(256), 0, slu_stream(stream), dy, scale, dx, N * C, H, W,
+                     (H + 1) / 2, (W + 1) / 2);
+  SLU_CHECK_LAUNCH();
+}

@@ -1,0 +1,144 @@
+// Convolution weight gradient on the fp32 matrix cores (gfx950).
+//
+//   dW[co][ci][ti][tj] = sum_{n,y,x} da[n,co,y,x] * in[n,ci, y - pad + ti*dil, x - pad + tj*dil]
+//
+// GEMM view: M = output channels, N = input channels, K = pixels.  v_mfma_f32_32x32x2_f32 wants the M / N
+// index on the lane and two K values per instruction, so both operands are read from channel-last copies
+// (da_t [N,HW,Cop], in_t [N,HW,Cip], Cop/Cip = channel counts padded to 32; written by slu_nchw_to_nhwc /
+// slu_gather_nhwc): lane l loads channel (l & 31) of pixel (x + (l >> 5)) -- two 128-byte segments per load,
+// no LDS.  One wave accumulates a 32 x 32 x (KS*KS taps) block of dW over a strided set of pixel runs; the
+// tap-shifted B operands of neighbouring K-steps overlap and are served by L1/L2.  Partial blocks are added
+// to a tap-major image dWp[co][tap][ci] with float atomics (contiguous 128-byte segments per instruction;
+// summation order is not reproducible bit for bit), then unpacked to OIHW.
+#include "slu_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kRun = 32;   // pixel pairs per run (64 azimuth-adjacent pixels)
+
+template <int KS, int DIL, int PAD>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__ da_t, const float* __restrict__ in_t, int N, int H,
+                                                       int W, int Cop, int Cip, float* __restrict__ dWp) {
+  constexpr int T = KS * KS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hh = lane >> 5, jj = lane & 31;
+  const int cob = blockIdx.y, cib = blockIdx.z;
+  const long long HW = (long long)H * W;
+  const long long npairs = (long long)N * HW / 2;
+  const long long nruns = (npairs + kRun - 1) / kRun;
+  const long long worker = (long long)blockIdx.x * 4 + wave, nworkers = (long long)gridDim.x * 4;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  const float* abase = da_t + (size_t)cob * 32 + jj;
+  const float* bbase = in_t + (size_t)cib * 32 + jj;
+
+  for (long long run = worker; run < nruns; run += nworkers) {
+    const long long q0 = run * kRun;
+    const long long q1 = (q0 + kRun < npairs) ? q0 + kRun : npairs;
+    for (long long q = q0; q < q1; ++q) {
+      const long long pix = 2 * q;
+      const long long n = pix / HW;
+      const int rem = (int)(pix - n * HW);
+      const int y = rem / W, x = rem - y * W;          // x even, x + 1 < W (W even)
+      const float a = abase[(size_t)(pix + hh) * Cop];
+      float b[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int yy = y - PAD + (t / KS) * DIL, xx = x + hh - PAD + (t % KS) * DIL;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const size_t idx = ok ? (size_t)(n * HW + (long long)yy * W + xx) * Cip : 0;
+        const float v = bbase[idx];
+        b[t] = ok ? v : 0.0f;
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+    }
+  }
+
+  // D[i = co][j = ci]: lane & 31 = ci, register/half = co
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      atomicAdd(&dWp[((size_t)co * T + t) * Cip + cib * 32 + jj], acc[t][r]);
+    }
+}
+
+__global__ void wgrad_unpack_kernel(const float* __restrict__ dWp, int Cout, int Cin, int T, int Cip, float* __restrict__ dW, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(e % T);
+    const size_t r = e / T;
+    const int ci = (int)(r % Cin);
+    const int co = (int)(r / Cin);
+    dW[e] = dWp[((size_t)co * T + t) * Cip + ci];
+  }
+}
+
+// weights of the data-gradient conv: Wd[ci][co][KS-1-ti][KS-1-tj] = W[co][ci][ti][tj]   (all four kernel
+// families are symmetric: 2*pad == (KS-1)*dil, so dgrad is the same conv family with these weights)
+__global__ void dgrad_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int KS, float* __restrict__ wd, size_t total) {
+  const int T = KS * KS;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(e % T);
+    const size_t r = e / T;
+    const int co = (int)(r % Cout);
+    const int ci = (int)(r / Cout);
+    wd[e] = w[((size_t)co * Cin + ci) * T + (T - 1 - t)];
+  }
+}
+
+template <int KS, int DIL, int PAD>
+int launch_wgrad(const float* da_t, const float* in_t, int N, int H, int W, int Cop, int Cip, float* dWp, hipStream_t st) {
+  const int nb = (Cop / 32) * (Cip / 32);
+  const long long nruns = ((long long)N * H * W / 2 + kRun - 1) / kRun;
+  long long gx = 1024 / nb;
+  if (gx < 1) gx = 1;
+  if (gx * 4 > nruns) gx = (nruns + 3) / 4;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((wgrad_kernel<KS, DIL, PAD>), dim3((unsigned)gx, Cop / 32, Cip / 32), dim3(256), 0, st, da_t, in_t, N, H, W, Cop, Cip, dWp);
+  SLU_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" size_t slu_wgrad_packed_floats(int cout, int cin, int ksize) {
+  if (cout <= 0 || cin <= 0 || ksize <= 0) return 0;
+  return (size_t)((cout + 31) / 32 * 32) * ksize * ksize * ((cin + 31) / 32 * 32);
+}
+
+extern "C" int slu_conv2d_wgrad(const float* da_t, const float* in_t, int N, int H, int W, int Cout, int Cin, int ksize, int dil, int pad,
+                                float* dWp, float* dW, slu_stream_t stream) {
+  if (!da_t || !in_t || !dWp || !dW || N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0) return SLU_EINVAL;
+  if (W & 1) return SLU_EUNSUPPORTED;
+  if (Cout > 65535 * 32 || Cin > 65535 * 32) return SLU_EUNSUPPORTED;
+  const int Cop = (Cout + 31) / 32 * 32, Cip = (Cin + 31) / 32 * 32;
+  hipStream_t st = slu_stream(stream);
+  if (hipMemsetAsync(dWp, 0, slu_wgrad_packed_floats(Cout, Cin, ksize) * sizeof(float), st) != hipSuccess) return SLU_ELAUNCH;
+  int rc;
+  if (ksize == 1 && dil == 1 && pad == 0) rc = launch_wgrad<1, 1, 0>(da_t, in_t, N, H, W, Cop, Cip, dWp, st);
+  else if (ksize == 3 && dil == 1 && pad == 1) rc = launch_wgrad<3, 1, 1>(da_t, in_t, N, H, W, Cop, Cip, dWp, st);
+  else if (ksize == 3 && dil == 2 && pad == 2) rc = launch_wgrad<3, 2, 2>(da_t, in_t, N, H, W, Cop, Cip, dWp, st);
+  else if (ksize == 2 && dil == 2 && pad == 1) rc = launch_wgrad<2, 2, 1>(da_t, in_t, N, H, W, Cop, Cip, dWp, st);
+  else return SLU_EUNSUPPORTED;
+  if (rc != SLU_OK) return rc;
+  const size_t total = (size_t)Cout * Cin * ksize * ksize;
+  const unsigned g = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(g), dim3(256), 0, st, dWp, Cout, Cin, ksize * ksize, Cip, dW, total);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_dgrad_weight(const float* w, int cout, int cin, int ksize, float* wd, slu_stream_t stream) {
+  if (!w || !wd || cout <= 0 || cin <= 0 || ksize <= 0) return SLU_EINVAL;
+  const size_t total = (size_t)cout * cin * ksize * ksize;
+  const unsigned g = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(dgrad_weight_kernel, dim3(g), dim3(256), 0, slu_stream(stream), w, cout, cin, ksize, wd, total);
+  SLU_CHECK_LAUNCH();
+}

@@ -328,3 +328,156 @@ def softmax_loss_bwd(probs, labels=None, dense=None, w_dense: float = 1.0, w_nll
     check(_lib.load().slu_softmax_loss_bwd(probs.data_ptr(), _ptr(labels), _ptr(dense), float(w_dense), float(w_nll), float(clamp),
                                            _ptr(gout), b, c, h * w, g.data_ptr(), _stream()), "slu_softmax_loss_bwd")
     return g
+
+
+# ------------------------------------------------------------------------------------------------
+# training-side kernels
+# ------------------------------------------------------------------------------------------------
+def _fill_srcs(arr, srcs):
+    n = h = w = None
+    for i, s in enumerate(srcs):
+        t = _req(s.tensor, f"src[{i}]")
+        sn, sc, sh, sw = t.shape
+        if s.pixel_shuffle:
+            sh, sw = sh * 2, sw * 2
+        if n is None:
+            n, h, w = sn, sh, sw
+        elif (sn, sh, sw) != (n, h, w):
+            raise RuntimeError(f"src[{i}]: size mismatch")
+        if s.scale is not None:
+            _req(s.scale, f"src[{i}].scale")
+            if tuple(s.scale.shape) != (sn, sc):
+                raise RuntimeError(f"src[{i}].scale: expected {(sn, sc)}")
+        arr[i].ptr, arr[i].scale, arr[i].C, arr[i].pixel_shuffle = t.data_ptr(), _ptr(s.scale), sc, 1 if s.pixel_shuffle else 0
+    return n, h, w
+
+
+def bn_stats(y: torch.Tensor):
+    """(sum f64[C], sumsq f64[C]) over (N,H,W)."""
+    _req(y, "y")
+    n, c, h, w = y.shape
+    s = torch.zeros(c, dtype=torch.float64, device=y.device)
+    q = torch.zeros(c, dtype=torch.float64, device=y.device)
+    check(_lib.load().slu_bn_stats(y.data_ptr(), n, c, h * w, s.data_ptr(), q.data_ptr(), _stream()), "slu_bn_stats")
+    return s, q
+
+
+def bn_bwd_reduce(dz, y, mean, invstd):
+    """(sum dz, sum dz*xhat) per channel, f64."""
+    for t, nme in ((dz, "dz"), (y, "y"), (mean, "mean"), (invstd, "invstd")):
+        _req(t, nme)
+    if dz.shape != y.shape:
+        raise RuntimeError("dz / y shape mismatch")
+    n, c, h, w = y.shape
+    s1 = torch.zeros(c, dtype=torch.float64, device=y.device)
+    s2 = torch.zeros(c, dtype=torch.float64, device=y.device)
+    check(_lib.load().slu_bn_bwd_reduce(dz.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), n, c, h * w, s1.data_ptr(),
+                                        s2.data_ptr(), _stream()), "slu_bn_bwd_reduce")
+    return s1, s2
+
+
+def affine(y, a=None, b=None, resid=None):
+    """z = a[c]*y + b[c] + resid."""
+    _req(y, "y")
+    n, c, h, w = y.shape
+    for t, nme in ((a, "a"), (b, "b")):
+        if t is not None:
+            _req(t, nme)
+            if t.numel() != c:
+                raise RuntimeError(f"{nme}: expected {c} elements")
+    if resid is not None:
+        _req(resid, "resid")
+        if resid.shape != y.shape:
+            raise RuntimeError("resid shape mismatch")
+    z = torch.empty_like(y)
+    check(_lib.load().slu_affine_fwd(y.data_ptr(), _ptr(a), _ptr(b), _ptr(resid), z.data_ptr(), n, c, h * w, _stream()), "slu_affine_fwd")
+    return z
+
+
+def act_affine_bwd(dz, y=None, k1=None, k2=None, k3=None, slope=None, want_dbias=True):
+    """da = (k1*dz + k2 + k3*y) * leaky'(y);  dbias f64[C] = sum da."""
+    _req(dz, "dz")
+    n, c, h, w = dz.shape
+    if y is not None:
+        _req(y, "y")
+        if y.shape != dz.shape:
+            raise RuntimeError("y shape mismatch")
+    for t, nme in ((k1, "k1"), (k2, "k2"), (k3, "k3")):
+        if t is not None:
+            _req(t, nme)
+            if t.numel() != c:
+                raise RuntimeError(f"{nme}: expected {c} elements")
+    da = torch.empty_like(dz)
+    db = torch.zeros(c, dtype=torch.float64, device=dz.device) if want_dbias else None
+    check(_lib.load().slu_act_affine_bwd(dz.data_ptr(), _ptr(y), _ptr(k1), _ptr(k2), _ptr(k3), 0.0 if slope is None else float(slope),
+                                         0 if slope is None else 1, n, c, h * w, da.data_ptr(), _ptr(db), _stream()), "slu_act_affine_bwd")
+    return da, db
+
+
+def nchw_to_nhwc(x):
+    _req(x, "x")
+    n, c, h, w = x.shape
+    cp = (c + 31) // 32 * 32
+    out = torch.empty((n, h * w, cp), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_nchw_to_nhwc(x.data_ptr(), n, c, h * w, out.data_ptr(), _stream()), "slu_nchw_to_nhwc")
+    return out
+
+
+def gather_nhwc(srcs: Sequence[ConvSource]):
+    arr = (_lib.ConvSrc * _lib.MAX_SRC)()
+    n, h, w = _fill_srcs(arr, srcs)
+    cin = sum(s.tensor.shape[1] // 4 if s.pixel_shuffle else s.tensor.shape[1] for s in srcs)
+    cp = (cin + 31) // 32 * 32
+    out = torch.empty((n, h * w, cp), dtype=torch.float32, device=srcs[0].tensor.device)
+    check(_lib.load().slu_gather_nhwc(arr, len(srcs), n, h, w, out.data_ptr(), _stream()), "slu_gather_nhwc")
+    return out
+
+
+def split_grad(dcat, cbeg: int, src_shape, pixel_shuffle: bool, scale=None):
+    _req(dcat, "dcat")
+    n, ccat, h, w = dcat.shape
+    sn, sc, sh, sw = src_shape
+    if sn != n or (sh, sw) != ((h // 2, w // 2) if pixel_shuffle else (h, w)):
+        raise RuntimeError("split_grad: source shape does not match the concatenated gradient")
+    if scale is not None:
+        _req(scale, "scale")
+    out = torch.empty(tuple(src_shape), dtype=torch.float32, device=dcat.device)
+    check(_lib.load().slu_split_grad(dcat.data_ptr(), n, ccat, int(cbeg), h, w, sc, 1 if pixel_shuffle else 0, _ptr(scale), out.data_ptr(),
+                                     _stream()), "slu_split_grad")
+    return out
+
+
+def avgpool3s2_bwd(dy, scale, x_shape):
+    _req(dy, "dy")
+    n, c, h, w = x_shape
+    if tuple(dy.shape) != (n, c, (h + 1) // 2, (w + 1) // 2):
+        raise RuntimeError("avgpool3s2_bwd: dy shape mismatch")
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    check(_lib.load().slu_avgpool3s2_bwd(dy.data_ptr(), _ptr(scale), dx.data_ptr(), n, c, h, w, _stream()), "slu_avgpool3s2_bwd")
+    return dx
+
+
+def dgrad_weight(weight):
+    """[Cout,Cin,k,k] -> [Cin,Cout,k,k] with taps mirrored: the weights of the data-gradient conv."""
+    _req(weight, "weight")
+    cout, cin, k, _ = weight.shape
+    wd = torch.empty((cin, cout, k, k), dtype=torch.float32, device=weight.device)
+    check(_lib.load().slu_dgrad_weight(weight.data_ptr(), cout, cin, k, wd.data_ptr(), _stream()), "slu_dgrad_weight")
+    return wd
+
+
+def conv2d_wgrad(da_t, in_t, n, h, w, cout, cin, ksize, dil, pad):
+    """dW [cout,cin,k,k] from channel-last da_t [N,HW,Cop] and in_t [N,HW,Cip]."""
+    _req(da_t, "da_t")
+    _req(in_t, "in_t")
+    cop, cip = (cout + 31) // 32 * 32, (cin + 31) // 32 * 32
+    if tuple(da_t.shape) != (n, h * w, cop) or tuple(in_t.shape) != (n, h * w, cip):
+        raise RuntimeError("conv2d_wgrad: operand shapes do not match")
+    if w % 2:
+        raise RuntimeError("conv2d_wgrad: W must be even")
+    lib = _lib.load()
+    scratch = torch.empty(lib.slu_wgrad_packed_floats(cout, cin, ksize), dtype=torch.float32, device=da_t.device)
+    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=da_t.device)
+    check(lib.slu_conv2d_wgrad(da_t.data_ptr(), in_t.data_ptr(), n, h, w, cout, cin, ksize, dil, pad, scratch.data_ptr(), dw.data_ptr(),
+                               _stream()), "slu_conv2d_wgrad")
+    return dw

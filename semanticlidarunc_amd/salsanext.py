@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .autograd import AvgPoolFn, ConvLayerFn, LayerCfg
 from .ops import ConvSource
 
 _SLOPE = 0.01  # nn.LeakyReLU() default used throughout the reference model
@@ -30,11 +31,12 @@ class _Prepared:
     """Device-side derived constants of one conv (+ its BatchNorm): the MFMA-ordered weight image and
     the folded BN affine.  Rebuilt lazily whenever the owning parameters/buffers change."""
 
-    __slots__ = ("key", "wpack", "bn_key", "bn_a", "bn_b")
+    __slots__ = ("key", "wpack", "bn_key", "bn_a", "bn_b", "dgrad")
 
     def __init__(self):
         self.key = self.bn_key = None
         self.wpack = self.bn_a = self.bn_b = None
+        self.dgrad = {}          # packed data-gradient weights, keyed by the weight version
 
 
 def _tkey(*ts):
@@ -54,21 +56,27 @@ class _FusedBlock(nn.Module):
         if p.key != wkey:
             p.wpack = ops.pack_conv_weight(conv.weight.detach().contiguous())
             p.key = wkey
+        k = conv.kernel_size[0]
+        slope = _SLOPE if act else None
+        wants_grad = torch.is_grad_enabled() and (
+            conv.weight.requires_grad or any(s.tensor.requires_grad for s in srcs)
+            or (resid is not None and resid.requires_grad) or (bn is not None and bn.weight.requires_grad))
+        if wants_grad or (bn is not None and bn.training):
+            # autograd node per layer (also the train-mode BatchNorm forward): conv -> stats -> affine
+            cfg = LayerCfg(k, conv.dilation[0], conv.padding[0], slope, [s.scale for s in srcs],
+                           [s.pixel_shuffle for s in srcs], bn, conv.out_channels, p.wpack, p.dgrad)
+            return ConvLayerFn.apply(cfg, conv.weight, conv.bias, None if bn is None else bn.weight,
+                                     None if bn is None else bn.bias, resid, *[s.tensor for s in srcs])
         bn_a = bn_b = None
         if bn is not None:
-            if bn.training:
-                raise NotImplementedError(
-                    "train-mode BatchNorm (batch statistics) is not available on the HIP path yet; "
-                    "call model.eval() (MC-dropout sampling keeps BatchNorm in eval mode anyway)")
             bkey = _tkey(bn.weight, bn.bias, bn.running_mean, bn.running_var)
             if p.bn_key != bkey:
                 p.bn_a, p.bn_b = ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
                 p.bn_key = bkey
             bn_a, bn_b = p.bn_a, p.bn_b
-        k = conv.kernel_size[0]
         return ops.conv2d_fused(srcs, p.wpack, conv.out_channels, k, conv.dilation[0], conv.padding[0],
                                 bias=None if conv.bias is None else conv.bias.detach(),
-                                slope=_SLOPE if act else None, bn_a=bn_a, bn_b=bn_b, resid=resid)
+                                slope=slope, bn_a=bn_a, bn_b=bn_b, resid=resid)
 
 
 def _draw(drop: nn.Dropout2d, n: int, c: int, device, override: Optional[Dict[str, torch.Tensor]], name: str):
@@ -133,7 +141,8 @@ class ResBlock(_FusedBlock):
         if self.drop_out:
             s = _draw(self.dropout, full.shape[0], full.shape[1], full.device, _scales, _name + ".dropout")
         if self.pooling:
-            return ops.avgpool3s2(full, s), full
+            pooled = AvgPoolFn.apply(full, s) if (torch.is_grad_enabled() and full.requires_grad) else ops.avgpool3s2(full, s)
+            return pooled, full
         return full, s
 
 
@@ -216,8 +225,6 @@ class SalsaNext(_FusedBlock):
                                f"'{x.device}' and there is no CPU fallback")
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise RuntimeError("SalsaNext needs H and W divisible by 16")
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("backward through the HIP path is not implemented yet; use torch.no_grad() / eval()")
         x = x.contiguous().float()
         d = self.downCntx(x)
         d = self.downCntx2(d)

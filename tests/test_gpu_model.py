@@ -93,7 +93,8 @@ def test_weight_update_invalidates_packed_cache(cuda):
         m.logits.bias.mul_(2.0)
         y1 = m(x)
     assert float((y1 - 2.0 * y0).abs().max()) <= 1e-4
-    m.train()
-    with pytest.raises(NotImplementedError):
-        with torch.no_grad():
-            m(x)
+    m.train()                                    # train-mode BatchNorm: batch statistics, running stats move
+    before = m.downCntx.bn1.running_mean.clone()
+    with torch.no_grad():
+        m(x)
+    assert not torch.equal(before, m.downCntx.bn1.running_mean)

@@ -107,6 +107,40 @@ def main():
     assert d <= 2e-4
     ref.eval()
 
+    # ---------------- training step: train-mode BatchNorm + dropout multipliers, forward + backward ----------------
+    x3, _ = synthetic_scan(2, 64, 128, seed=13)
+    x3 = x3.requires_grad_(True)
+    scales3 = osalsa.draw_dropout_scales(2, 0.2, torch.Generator().manual_seed(6))
+    ref_b = RefSalsaNext(20, 5)
+    ref_b.load_state_dict(sd)
+    ref_b.train()
+    mods_b = dict(ref_b.named_modules())
+    for name, s in scales3.items():
+        mods_b[name].forward = (lambda t, s=s: t * s)
+    proj = torch.randn(2, 20, 64, 128, generator=torch.Generator().manual_seed(7))
+    out_b = ref_b(x3)
+    ((out_b * proj).sum() / 64.0).backward()
+    pnames = ["downCntx.conv1.weight", "downCntx.conv1.bias", "downCntx.bn1.weight", "downCntx.bn1.bias", "downCntx2.conv3.weight",
+              "resBlock1.conv5.weight", "resBlock2.conv4.weight", "resBlock5.bn4.weight", "upBlock3.conv1.weight",
+              "upBlock4.conv1.weight", "upBlock4.bn4.bias", "logits.weight", "logits.bias"]
+    params_b = dict(ref_b.named_parameters())
+    sd_o = {k: v.clone().requires_grad_(v.is_floating_point() and k in params_b) for k, v in sd.items()}
+    x3o = x3.detach().clone().requires_grad_(True)
+    out_o, bn_stats_o = osalsa.salsanext_forward(sd_o, x3o, scales3, bn_train=True, return_bn_stats=True)
+    ((out_o * proj).sum() / 64.0).backward()
+    worst = max(maxdiff(sd_o[k].grad, params_b[k].grad) / (1e-6 + float(params_b[k].grad.abs().max())) for k in params_b)
+    print(f"train step: logits |d|={maxdiff(out_o.detach(), out_b.detach()):.2e}  dx |d|={maxdiff(x3o.grad, x3.grad):.2e}  "
+          f"worst relative param-grad diff={worst:.2e}")
+    assert maxdiff(out_o.detach(), out_b.detach()) <= 2e-4 and worst <= 2e-3
+    gnorm = {k: float(params_b[k].grad.norm()) for k in params_b}
+    save("train_step_2x5x64x128", x=x3.detach(), proj_seed=7, logits=out_b.detach()[:, :, ::2, ::4], grad_x=x3.grad,
+         grad_norms=np.array([gnorm[k] for k in sorted(gnorm)]),
+         running_mean_downCntx_bn1=ref_b.state_dict()["downCntx.bn1.running_mean"],
+         running_var_downCntx_bn1=ref_b.state_dict()["downCntx.bn1.running_var"],
+         running_var_resBlock5_bn4=ref_b.state_dict()["resBlock5.bn4.running_var"],
+         **{"scale:" + k: v.reshape(v.shape[0], v.shape[1]) for k, v in scales3.items()},
+         **{"grad:" + k: params_b[k].grad for k in pnames})
+
     # ---------------- MC reduction ----------------
     g = torch.Generator().manual_seed(21)
     mc_logits = torch.randn(4, 1, 20, 4, 64, generator=g) * 3.0
