@@ -1,0 +1,105 @@
+"""CPU, gloo, world_size 2: the data-parallel glue (flat gradient all-reduce through the optimizer hook,
+parameter broadcast, buffer averaging, metric all-reduce, sharded sampler)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from semanticlidarunc_amd.distributed import (FlatGradAllReduce, ShardedSampler, all_reduce_metrics, average_buffers,
+                                               broadcast_parameters, init_from_env)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _net(seed):
+    torch.manual_seed(seed)
+    return nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.BatchNorm2d(4), nn.ReLU(), nn.Conv2d(4, 2, 1), nn.Linear(8, 8, bias=False))
+
+
+class _Acc:
+    pass
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    assert init_from_env("gloo") == (rank, rank, world)
+    model = _net(seed=10 + rank)                      # ranks start different on purpose
+    broadcast_parameters(model, src=0)
+    ref = _net(seed=10)                               # single-process twin of rank 0's init
+    for a, b in zip(model.state_dict().values(), ref.state_dict().values()):
+        assert torch.equal(a, b)
+    model[4].weight.requires_grad_(True)              # a parameter that never receives a gradient (grad is None)
+    g = torch.Generator().manual_seed(0)
+    x_all, y_all = torch.randn(8, 3, 6, 8, generator=g), torch.randn(8, 2, 6, 8, generator=g)
+    sampler = ShardedSampler(8, rank, world, seed=3)
+    idx = list(iter(sampler))
+    assert len(idx) == 4
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    red = FlatGradAllReduce(model.parameters())
+    red.attach_to_optimizer(opt)
+    model.eval()                                      # frozen BN: local-mean losses average exactly to the global mean
+    loss = (model[:4](x_all[idx]) - y_all[idx]).square().mean()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()                                        # hook all-reduces, then identical update everywhere
+    # single-process reference on the union of both shards
+    other = list(iter(ShardedSampler(8, 1 - rank, world, seed=3)))
+    assert sorted(idx + other) == list(range(8))
+    ref.eval()
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    (ref[:4](x_all[idx + other]) - y_all[idx + other]).square().mean().backward()
+    ropt.step()
+    for (k, a), b in zip(model.state_dict().items(), ref.state_dict().values()):
+        assert torch.allclose(a, b, atol=1e-6), k
+    assert model[4].weight.grad is not None and float(model[4].weight.grad.abs().max()) == 0.0
+    # buffers / metrics
+    model[1].running_mean.fill_(float(rank))
+    average_buffers(model)
+    assert torch.allclose(model[1].running_mean, torch.full((4,), 0.5))
+    iou, ece = _Acc(), _Acc()
+    iou.confmat = torch.full((3, 3), rank + 1, dtype=torch.int64)
+    ece._count = torch.tensor([1, 2], dtype=torch.int64) * (rank + 1)
+    ece._sum_correct = torch.tensor([0.5, 1.0], dtype=torch.float64)
+    ece._sum_conf = torch.tensor([0.25, 0.5], dtype=torch.float64)
+    all_reduce_metrics(iou, ece)
+    assert torch.equal(iou.confmat, torch.full((3, 3), 3, dtype=torch.int64))
+    assert ece._count.tolist() == [3, 6] and ece._sum_conf.tolist() == [0.5, 1.0]
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_two_rank_data_parallel_step_equals_single_process():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(out.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_single_process_is_a_no_op():
+    m = _net(1)
+    red = FlatGradAllReduce(m.parameters())
+    assert red.nbytes == 4 * sum(p.numel() for p in m.parameters())
+    m[:4](torch.randn(2, 3, 4, 4)).sum().backward()
+    before = [p.grad.clone() if p.grad is not None else None for p in m.parameters()]
+    red.reduce()
+    for a, p in zip(before, m.parameters()):
+        assert (a is None and p.grad is None) or torch.equal(a, p.grad)
+    s = ShardedSampler(10, 0, 1, shuffle=False)
+    assert list(iter(s)) == list(range(10)) and len(s) == 10

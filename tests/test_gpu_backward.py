@@ -184,3 +184,28 @@ def test_retain_graph_reentrant_and_eval_mode_grads(cuda):
     assert _rel(g1[0].cpu(), sd["logits.weight"].grad) <= 1e-3 and _rel(g1[1].cpu(), sd["downCntx.conv1.weight"].grad) <= 1e-3
     with torch.no_grad():
         assert not model(x).requires_grad
+
+
+def test_full_size_training_step_against_oracle(cuda):
+    """BASELINE configs[1] shape at batch 2 (64x2048): train-mode forward + fused SalsaNext loss + backward.
+    Loss terms are well conditioned (1e-3 relative); gradients are compared by direction (cosine >= 0.999)."""
+    from oracle import losses as olosses
+    from semanticlidarunc_amd.loss import salsanext_loss
+    from semanticlidarunc_amd.testing import synthetic_scan
+    model = seeded_model(SalsaNext).to(cuda).train()
+    x, y = synthetic_scan(2, 64, 2048, seed=21)
+    scales = osalsa.draw_dropout_scales(2, 0.2, torch.Generator().manual_seed(9))
+    loss, nll, ls = salsanext_loss(model.forward_with_dropout_scales(x.to(cuda), scales), y.to(cuda), 1.0, 1.0, 0)
+    loss.backward()
+    pn = {k for k, _ in model.named_parameters()}
+    sd = {k: (v.detach().cpu().clone().requires_grad_(True) if k in pn else v.detach().cpu().clone()) for k, v in seeded_model(SalsaNext).state_dict().items()}
+    lo, nll_o, ls_o = olosses.salsanext_loss(osalsa.salsanext_forward(sd, x, scales, bn_train=True), y)
+    lo.backward()
+    assert abs(float(nll) - float(nll_o)) <= 1e-3 * float(nll_o) and abs(float(ls) - float(ls_o)) <= 1e-3
+    params = dict(model.named_parameters())
+    for k in ("downCntx.conv2.weight", "resBlock1.conv3.weight", "resBlock4.conv5.weight", "upBlock1.conv1.weight", "upBlock4.conv4.weight",
+              "logits.weight", "resBlock2.bn2.weight", "upBlock3.bn1.bias"):
+        a, b = params[k].grad.cpu().flatten().double(), sd[k].grad.flatten().double()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        assert cos >= 0.999, (k, cos)
+        assert abs(float(a.norm()) / float(b.norm()) - 1.0) <= 0.03, k

@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Training-step timing (BASELINE configs[1] / configs[3] shape): B scans of 64x2048x5 per GPU, fp32,
+SalsaNext in train mode (batch-statistics BatchNorm, live Dropout2d) -> fused softmax + NLL + Lovasz loss ->
+backward (dgrad / wgrad on the fp32 matrix cores) -> [flat RCCL gradient all-reduce] -> AdamW.
+
+    python tools/train_bench.py [--batch 4 --steps 5 --warmup 2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from semanticlidarunc_amd.distributed import FlatGradAllReduce, broadcast_parameters, init_from_env  # noqa: E402
+from semanticlidarunc_amd.loss import salsanext_loss  # noqa: E402
+from semanticlidarunc_amd.salsanext import SalsaNext  # noqa: E402
+from semanticlidarunc_amd.testing import seeded_model, synthetic_scan  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--width", type=int, default=2048)
+    a = ap.parse_args()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    rank, _, world = init_from_env(device=dev)
+    model = seeded_model(SalsaNext).to(dev).train()
+    broadcast_parameters(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    red = FlatGradAllReduce(model.parameters())
+    red.attach_to_optimizer(opt)
+    x, y = synthetic_scan(a.batch, a.height, a.width, seed=1234 + rank)
+    x, y = x.to(dev), y.to(dev)
+    torch.manual_seed(7 + rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, nll, ls = salsanext_loss(model(x), y, 1.0, 1.0, 0)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        flops = 3 * 124.60e9 * a.batch * (a.height * a.width) / (64 * 2048)
+        print(json.dumps({"metric": "training scans/s (fwd + loss + bwd + AdamW)", "value": round(a.batch * world * a.steps / dt, 3),
+                          "unit": "scans/s", "n_gpus": world, "ms_per_step": round(ms, 2), "batch_per_gpu": a.batch, "dtype": "f32",
+                          "conv_tflops_per_gpu(3x fwd flops)": round(flops / (ms * 1e-3) / 1e12, 2), "loss": round(float(loss), 5),
+                          "grad_allreduce_mb": round(red.nbytes / 1e6, 1)}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
