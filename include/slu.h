@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 1
+#define SLU_ABI_VERSION 2
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -73,7 +73,16 @@ typedef struct slu_conv_desc {   /* HOST struct */
   const float* bn_b;
   const float* resid;    /* [N, Cout, H, W] or NULL                                              */
   float* out;            /* [N, Cout, H, W]                                                      */
+  int32_t precision;     /* SLU_CONV_FP32 (exact fp32 MFMA) or SLU_CONV_F16X3 (split-fp16, see below)             */
 } slu_conv_desc;
+
+/* precision of the multiply-accumulate inside slu_conv2d_fwd (inputs, outputs and accumulation are fp32 either way):
+ *   SLU_CONV_FP32  : v_mfma_f32_32x32x2_f32, bit-for-bit a k-ordered fmaf chain; wpack from slu_pack_conv_weight, ck = slu_conv_ck
+ *   SLU_CONV_F16X3 : every fp32 operand x is split x = hi + lo (two fp16), products hi*hi + hi*lo + lo*hi on
+ *                    v_mfma_f32_32x32x16_f16 (fp32 accumulate): ~2^-22 relative error per product, 5.3x fewer MFMA
+ *                    cycles; |x| must stay below 65504; wpack from slu_pack_conv_weight_f16x3, ck = 16 */
+#define SLU_CONV_FP32  0
+#define SLU_CONV_F16X3 1
 
 /* K-chunk (input channels staged per LDS round) used for a kernel family. */
 int slu_conv_ck(int ksize);
@@ -82,6 +91,9 @@ size_t slu_packed_weight_floats(int cout, int cin, int ksize, int ck);
 /* w: [cout, cin, ksize, ksize] (torch OIHW) -> out: packed image.  Re-run after every weight update. */
 int slu_pack_conv_weight(const float* w, int cout, int cin, int ksize, int ck, float* out, slu_stream_t stream);
 int slu_conv2d_fwd(const slu_conv_desc* desc, slu_stream_t stream);
+/* split-fp16 weight image (bytes) and its packer (w: [cout,cin,k,k] fp32 OIHW) */
+size_t slu_packed_weight_bytes_f16x3(int cout, int cin, int ksize);
+int slu_pack_conv_weight_f16x3(const float* w, int cout, int cin, int ksize, void* out, slu_stream_t stream);
 /* name of the kernel instantiation slu_conv2d_fwd launches for `desc` (as rocprofv3 prints it); HOST buf >= 64 bytes */
 int slu_conv2d_kernel_name(const slu_conv_desc* desc, char* buf, size_t buflen);
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("has_act", C.c_int32), ("slope", C.c_float),
         ("bn_a", C.c_void_p), ("bn_b", C.c_void_p),
         ("resid", C.c_void_p), ("out", C.c_void_p),
+        ("precision", C.c_int32),
     ]
 
 
@@ -47,6 +48,8 @@ SIGNATURES = {
     "slu_packed_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "slu_pack_conv_weight": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
     "slu_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), c_stream]),
+    "slu_packed_weight_bytes_f16x3": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "slu_pack_conv_weight_f16x3": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_stream]),
     "slu_conv2d_kernel_name": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, C.c_size_t]),
     "slu_bn_fold": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_int, c_f32p, c_f32p, c_stream]),
     "slu_avgpool3s2_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),

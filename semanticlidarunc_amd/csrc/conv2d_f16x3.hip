@@ -1,0 +1,335 @@
+// Split-fp16 ("f16x3") variant of the fused conv (same fusion, same launch arguments, same epilogue as
+// conv2d.hip): every fp32 operand is split x = hi + lo with hi = fp16(x), lo = fp16(x - hi), and each K=16
+// step issues three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate).  The dropped lo*lo
+// term is ~2^-22 relative, so results agree with the exact-fp32 kernel to fp32-level accuracy while the
+// matrix-core time drops 5.3x (3 x 32 cycles per 16 channels x 32 x 32 instead of 8 x 64), which moves the
+// 3x3 / 2x2 convs of the range-image stack from MFMA-bound towards HBM-bound.
+//
+// LDS images (channel-innermost so one ds_read_b128 is one MFMA operand):
+//   B: [2 groups of 8 channels][rows][cols][8 x fp16]  hi and lo  -- lane (pixel r, half h) reads record
+//      (group h, pixel r + tap offset): consecutive lanes = consecutive 16-byte records, conflict-free
+//   A: [channel block][tap][64 lanes][8 x fp16] hi and lo, pre-packed by slu_pack_conv_weight_f16x3
+// Staging converts fp32 -> (hi, lo) on the fly: a thread loads 8 channels x 4 adjacent pixels (eight 16-byte
+// loads, each coalesced along azimuth), and writes four 16-byte records per image in a rotated order so the
+// eight lanes of a ds_write_b128 group hit distinct banks.
+#include "conv_common.h"
+
+using namespace slu_conv;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int CK16 = 16;
+
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo) {
+  half8 h, l;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const _Float16 a = (_Float16)x[k];
+    h[k] = a;
+    l[k] = (_Float16)(x[k] - (float)a);
+  }
+  hi = __builtin_bit_cast(uint4, h);
+  lo = __builtin_bit_cast(uint4, l);
+}
+
+template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool GEN>
+__global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f16x3_kernel(const ConvArgs a, const float* __restrict__ resid,
+                                                                                           float* __restrict__ out) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int T = KS * KS;
+  constexpr int TW = 64, TH = WN * RPW, NB = 2 * RPW;
+  constexpr int XO = PAD ? 4 : 0;
+  constexpr int LW = TW + 2 * XO, LH = TH + 2 * PAD, LW4 = LW / 4;
+  constexpr int REC = LH * LW;                      // 16-byte records per 8-channel group
+  constexpr int MBLK = WM * MB;
+  constexpr int NITEM = 2 * LH * LW4, NI = (NITEM + NT - 1) / NT;       // (group, row, 4-pixel quad) items
+  constexpr int NWV = MBLK * T * 128, NW = (NWV + NT - 1) / NT;          // uint4 items of the weight tile
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* s_bh = reinterpret_cast<uint4*>(smem);     // [2][REC]
+  uint4* s_bl = s_bh + 2 * REC;
+  uint4* s_ah = s_bl + 2 * REC;                     // [MBLK][T][64]
+  uint4* s_al = s_ah + MBLK * T * 64;
+  float* s_epi = reinterpret_cast<float*>(s_al + MBLK * T * 64);        // bias | bn_a | bn_b
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int t = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = t & 7, qq = nwg >> 3, rr = nwg & 7;
+    t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (t >> 3);
+  }
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int n = t / a.tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int mblk0 = blockIdx.y * MBLK;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
+
+  if (tid < MBLK * 32) {
+    const int co = mblk0 * 32 + tid;
+    const bool ok = co < a.Cout;
+    s_epi[tid] = (ok && a.bias) ? a.bias[co] : 0.0f;
+    s_epi[MBLK * 32 + tid] = (ok && a.bn_a) ? a.bn_a[co] : 1.0f;
+    s_epi[2 * MBLK * 32 + tid] = (ok && a.bn_a) ? a.bn_b[co] : 0.0f;
+  }
+
+  const int hh = lane >> 5, jj = lane & 31;
+  const int bbase = hh * REC + (wn * RPW) * LW + jj + (XO - PAD);
+  const int abase = (wm * MB) * T * 64 + lane;
+  const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpack);
+
+  for (int q = 0; q < a.nchunks; ++q) {
+    __syncthreads();
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+    // ---- weight fragments of this chunk: MBLK contiguous runs of T*128 uint4 ([tap][hi|lo][lane]) ----
+    uint4 sw[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int e = tq + i * NT;
+      const int m = e / (T * 128);
+      const int r = e - m * (T * 128);
+      const bool ok = (NWV % NT == 0 || e < NWV) && mblk0 + m < a.nmblk;
+      const size_t off = ok ? ((size_t)(mblk0 + m) * a.nchunks + q) * (T * 128) + r : 0;
+      sw[i] = wsrc[off];
+      if (!ok) sw[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // ---- input tile: 16 channels, converted to (hi, lo) fp16 and transposed to channel-innermost ----
+    if (a.vec) {
+      Item<GEN> st[NI][8];
+      unsigned okm[NI], psm[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int e = tq + i * NT;
+        const int g2 = e / (LH * LW4);
+        const int rem = e - g2 * (LH * LW4);
+        const int r = rem / LW4;
+        const int c4 = rem - r * LW4;
+        const int gy = y0 + r - PAD, gx4 = x0 - XO + 4 * c4;
+        const bool pix_ok = (NITEM % NT == 0 || e < NITEM) && gy >= 0 && gy < a.H && gx4 >= 0 && gx4 < a.W;
+        okm[i] = 0; psm[i] = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int cg = q * CK16 + g2 * 8 + k;
+          const bool ok = pix_ok && cg < a.Cin;
+          bool ps;
+          fetch_item<GEN>(a, n, ok ? cg : 0, gy, gx4, ok, st[i][k], ps);
+          okm[i] |= (ok ? 1u : 0u) << k;
+          psm[i] |= (ps ? 1u : 0u) << k;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int e = tq + i * NT;
+        if (NITEM % NT == 0 || e < NITEM) {
+          const int g2 = e / (LH * LW4);
+          const int rem = e - g2 * (LH * LW4);
+          const int r = rem / LW4;
+          const int c4 = rem - r * LW4;
+          float4 v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = item_value<GEN>(st[i][k], (okm[i] >> k) & 1u, (psm[i] >> k) & 1u);
+          const int rec0 = g2 * REC + r * LW + 4 * c4;
+          const int rot = (c4 >> 1) & 3;            // rotated pixel order: the 8 lanes of a b128 write group hit distinct banks
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int p = (s + rot) & 3;
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = p == 0 ? v[k].x : (p == 1 ? v[k].y : (p == 2 ? v[k].z : v[k].w));
+            uint4 hi, lo;
+            split8(x, hi, lo);
+            s_bh[rec0 + p] = hi;
+            s_bl[rec0 + p] = lo;
+          }
+        }
+      }
+    } else {   // any W: element-wise (slow path, odd test shapes only)
+      for (int e = tq; e < 2 * REC; e += NT) {
+        const int g2 = e / REC;
+        const int rem = e - g2 * REC;
+        const int r = rem / LW;
+        const int c = rem - r * LW;
+        const int gy = y0 + r - PAD, gx = x0 + c - XO;
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int cg = q * CK16 + g2 * 8 + k;
+          x[k] = (cg < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? load_input(a, n, cg, gy, gx) : 0.0f;
+        }
+        uint4 hi, lo;
+        split8(x, hi, lo);
+        s_bh[e] = hi;
+        s_bl[e] = lo;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int e = tq + i * NT;
+      if (NWV % NT == 0 || e < NWV) {
+        const int m = e / (T * 128);
+        const int r = e - m * (T * 128);
+        const int tap = r >> 7, hl = (r >> 6) & 1, ln = r & 63;
+        (hl ? s_al : s_ah)[(m * T + tap) * 64 + ln] = sw[i];
+      }
+    }
+    __syncthreads();
+    // ---- one K=16 step per tap: 3 MFMAs per (channel block, pixel block) ----
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+      const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
+      half8 ah[MB], al[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        ah[i] = __builtin_bit_cast(half8, s_ah[abase + (i * T + tap) * 64]);
+        al[i] = __builtin_bit_cast(half8, s_al[abase + (i * T + tap) * 64]);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int rr = b >> 1, cb = b & 1;
+        const int idx = bbase + (rr + dy) * LW + cb * 32 + dx;
+        const half8 bh = __builtin_bit_cast(half8, s_bh[idx]);
+        const half8 bl = __builtin_bit_cast(half8, s_bl[idx]);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][b], 0, 0, 0);
+          acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][b], 0, 0, 0);
+          acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue (identical to the fp32 kernel: the D fragment layout does not depend on the input dtype) ----
+  const size_t plane = (size_t)a.H * a.W;
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int ml = wm * MB + i;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int gy = y0 + wn * RPW + (b >> 1), gx = x0 + (b & 1) * 32 + jj;
+      const bool pix_ok = gy < a.H && gx < a.W;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int co = mblk0 * 32 + cl;
+        const bool ok = pix_ok && co < a.Cout;
+        const size_t o = ok ? ((size_t)n * a.Cout + co) * plane + (size_t)gy * a.W + gx : 0;
+        float v = acc[i][b][r] + s_epi[cl];
+        if (a.has_act) v = v > 0.0f ? v : v * a.slope;
+        v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
+        if (resid) v += resid[o];
+        if (ok) out[o] = v;
+      }
+    }
+  }
+}
+
+// wpack16[mblk][chunk][tap][hi|lo][lane][8]: lane (r, h) holds W[co = 32 mblk + r][ci = 16 chunk + 8 h + j][tap], j = 0..7
+__global__ void pack_f16x3_kernel(const float* __restrict__ w, int cout, int cin, int ks, int nchunks, size_t total_frag,
+                                  uint4* __restrict__ out) {
+  const int T = ks * ks;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total_frag; e += (size_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(e & 63);
+    size_t r = e >> 6;
+    const int tap = (int)(r % T);
+    r /= T;
+    const int q = (int)(r % nchunks);
+    const int m = (int)(r / nchunks);
+    const int co = m * 32 + (lane & 31);
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = q * CK16 + 8 * (lane >> 5) + j;
+      x[j] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * T + tap] : 0.0f;
+    }
+    uint4 hi, lo;
+    split8(x, hi, lo);
+    const size_t base = (((size_t)m * nchunks + q) * T + tap) * 128;
+    out[base + lane] = hi;
+    out[base + 64 + lane] = lo;
+  }
+}
+
+template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool GEN>
+int launch_cfg16(ConvArgs& a, hipStream_t st) {
+  constexpr int TH = WN * RPW, MBLK = WM * MB, T = KS * KS, XO = PAD ? 4 : 0;
+  constexpr int REC = (TH + 2 * PAD) * (64 + 2 * XO);
+  constexpr size_t lds = (size_t)4 * REC * 16 + (size_t)2 * MBLK * T * 64 * 16 + (size_t)3 * MBLK * 32 * 4;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  a.tiles_x = (a.W + 63) / 64;
+  a.tiles_y = (a.H + TH - 1) / TH;
+  const long long gx = (long long)a.tiles_x * a.tiles_y * a.N;
+  const int gy = (a.nmblk + MBLK - 1) / MBLK;
+  if (gx <= 0 || gx > 0x7fffffffLL || gy > 65535) return SLU_EUNSUPPORTED;
+  auto kern = conv_f16x3_kernel<KS, DIL, PAD, MB, WM, WN, RPW, GEN>;
+  static bool attr_set = false;     // benign race: the call is idempotent
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SLU_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64 * WM * WN), lds, st, a, a.resid, a.out);
+  SLU_CHECK_LAUNCH();
+}
+
+template <int KS, int DIL, int PAD, bool GEN>
+int launch_tiles16(ConvArgs& a, int cfg, hipStream_t st) {
+  switch (cfg) {
+    case M32_TH8:  return launch_cfg16<KS, DIL, PAD, 1, 1, 4, 2, GEN>(a, st);
+    case M64_TH8:  return launch_cfg16<KS, DIL, PAD, 2, 1, 4, 2, GEN>(a, st);
+    case M128_TH4: return launch_cfg16<KS, DIL, PAD, 2, 2, 2, 2, GEN>(a, st);
+    case M32_TH4:  return launch_cfg16<KS, DIL, PAD, 1, 1, 4, 1, GEN>(a, st);
+    case M64_TH4:  return launch_cfg16<KS, DIL, PAD, 2, 1, 4, 1, GEN>(a, st);
+  }
+  return SLU_EUNSUPPORTED;
+}
+
+template <int KS, int DIL, int PAD>
+int launch_family16(ConvArgs& a, int cfg, hipStream_t st) {
+  return a.gen ? launch_tiles16<KS, DIL, PAD, true>(a, cfg, st) : launch_tiles16<KS, DIL, PAD, false>(a, cfg, st);
+}
+
+}  // namespace
+
+extern "C" size_t slu_packed_weight_bytes_f16x3(int cout, int cin, int ksize) {
+  if (cout <= 0 || cin <= 0 || ksize <= 0) return 0;
+  const size_t nmblk = (cout + 31) / 32, nchunks = (cin + CK16 - 1) / CK16;
+  return nmblk * nchunks * (size_t)(ksize * ksize) * 128 * 16;
+}
+
+extern "C" int slu_pack_conv_weight_f16x3(const float* w, int cout, int cin, int ksize, void* out, slu_stream_t stream) {
+  if (!w || !out) return SLU_EINVAL;
+  const size_t bytes = slu_packed_weight_bytes_f16x3(cout, cin, ksize);
+  if (bytes == 0) return SLU_EINVAL;
+  const size_t frags = bytes / 32;      // one (hi, lo) pair of uint4 per lane
+  const int nchunks = (cin + CK16 - 1) / CK16;
+  const unsigned blocks = (unsigned)((frags + 255) / 256 > 4096 ? 4096 : (frags + 255) / 256);
+  hipLaunchKernelGGL(pack_f16x3_kernel, dim3(blocks), dim3(256), 0, slu_stream(stream), w, cout, cin, ksize, nchunks, frags,
+                     reinterpret_cast<uint4*>(out));
+  SLU_CHECK_LAUNCH();
+}
+
+// called by slu_conv2d_fwd (conv2d.hip) when desc->precision == SLU_CONV_F16X3
+int slu_conv2d_fwd_f16x3_impl(const slu_conv_desc* d, hipStream_t st) {
+  ConvArgs a{};
+  const int rc = fill_args(d, a);
+  if (rc != SLU_OK) return rc;
+  const int cfg = choose_cfg(a);
+  if (d->ksize == 1 && d->dil == 1 && d->pad == 0) return launch_family16<1, 1, 0>(a, cfg, st);
+  if (d->ksize == 3 && d->dil == 1 && d->pad == 1) return launch_family16<3, 1, 1>(a, cfg, st);
+  if (d->ksize == 3 && d->dil == 2 && d->pad == 2) return launch_family16<3, 2, 2>(a, cfg, st);
+  if (d->ksize == 2 && d->dil == 2 && d->pad == 1) return launch_family16<2, 2, 1>(a, cfg, st);
+  return SLU_EUNSUPPORTED;
+}

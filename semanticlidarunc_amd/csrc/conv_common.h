@@ -1,0 +1,183 @@
+// Definitions shared by the conv kernels (fp32-exact and split-fp16): launch arguments, input addressing
+// (concatenated sources, PixelShuffle, folded-dropout multipliers), tile-shape choice.
+#pragma once
+#include <stdio.h>
+
+#include "slu_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace slu_conv {
+
+struct SrcDev {
+  const float* ptr;
+  const float* scale;
+  int C;       // channels of the stored tensor
+  int ps;      // pixel-shuffle source
+  int cbeg;    // first conv-input channel contributed
+  int ccount;  // number of conv-input channels contributed
+};
+
+struct ConvArgs {
+  SrcDev src[SLU_MAX_SRC];
+  int nsrc;
+  int N, H, W, Cin, Cout;
+  int tiles_x, tiles_y, nchunks, nmblk;
+  const float* wpack;
+  const float* bias;
+  const float* bn_a;
+  const float* bn_b;
+  const float* resid;
+  float* out;
+  float slope;
+  int has_act;
+  int vec;  // W % 4 == 0 and every base pointer 16-byte aligned: float4 staging path
+  int gen;  // some source is read through PixelShuffle or carries a multiplier
+};
+
+// Which source feeds conv-input channel cg (sources are channel-concatenated).
+struct SrcPick {
+  const float* ptr;
+  const float* scale;
+  int C, cl, ps;
+};
+__device__ __forceinline__ SrcPick pick_src(const ConvArgs& a, int cg) {
+  SrcPick p{a.src[0].ptr, a.src[0].scale, a.src[0].C, cg, a.src[0].ps};
+#pragma unroll
+  for (int s = 1; s < SLU_MAX_SRC; ++s)
+    if (s < a.nsrc && cg >= a.src[s].cbeg) p = SrcPick{a.src[s].ptr, a.src[s].scale, a.src[s].C, cg - a.src[s].cbeg, a.src[s].ps};
+  return p;
+}
+
+// one element (any W): used only when W % 4 != 0
+__device__ __forceinline__ float load_input(const ConvArgs& a, int n, int cg, int gy, int gx) {
+  const SrcPick p = pick_src(a, cg);
+  float v;
+  int cs;
+  if (!p.ps) {
+    cs = p.cl;
+    v = p.ptr[(((size_t)n * p.C + cs) * a.H + gy) * a.W + gx];
+  } else {
+    cs = p.cl * 4 + ((gy & 1) << 1) + (gx & 1);
+    v = p.ptr[(((size_t)n * p.C + cs) * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)];
+  }
+  if (p.scale) v *= p.scale[(size_t)n * p.C + cs];
+  return v;
+}
+
+// One float4 item of the input tile, held raw between its (unconditional, clamped-address) loads and the
+// LDS write so that no wait sits between the loads of different items.
+template <bool GEN>
+struct Item;
+template <>
+struct Item<false> {
+  float4 v;
+};
+template <>
+struct Item<true> {
+  float4 v;      // plain: 4 adjacent pixels; PixelShuffle: {even0, even1, odd0, odd1}
+  float ku, kw;  // folded-dropout multipliers (1 when the source has none)
+};
+
+// gx4 % 4 == 0, W % 4 == 0.  `ok` false -> address clamped to element 0 of the source (always mapped).
+template <bool GEN>
+__device__ __forceinline__ void fetch_item(const ConvArgs& a, int n, int cg, int gy, int gx4, bool ok, Item<GEN>& it, bool& is_ps) {
+  const SrcPick p = pick_src(a, cg);
+  if constexpr (!GEN) {
+    const size_t idx = ok ? (((size_t)n * p.C + p.cl) * a.H + gy) * a.W + gx4 : 0;
+    it.v = *reinterpret_cast<const float4*>(p.ptr + idx);
+    is_ps = false;
+  } else {
+    const size_t hp = (size_t)(a.H >> 1) * (a.W >> 1);
+    const int cs = p.ps ? p.cl * 4 + ((gy & 1) << 1) : p.cl;
+    const size_t base = ((size_t)n * p.C + cs);
+    size_t i0 = p.ps ? base * hp + (size_t)(gy >> 1) * (a.W >> 1) + (gx4 >> 1) : (base * a.H + gy) * a.W + gx4;
+    size_t i1 = p.ps ? i0 + hp : i0 + 2;      // second 8-byte half: next stored channel / next two pixels
+    if (!ok) { i0 = 0; i1 = 0; }
+    const float2 u = *reinterpret_cast<const float2*>(p.ptr + i0);
+    const float2 w = *reinterpret_cast<const float2*>(p.ptr + i1);
+    it.v = make_float4(u.x, u.y, w.x, w.y);
+    const bool hs = ok && p.scale != nullptr;
+    const float* sp = hs ? p.scale + base : a.wpack;   // any mapped address when there is no multiplier
+    const float k0 = sp[0];
+    const float k1 = sp[(hs && p.ps) ? 1 : 0];
+    it.ku = hs ? k0 : 1.0f;
+    it.kw = hs ? k1 : 1.0f;
+    is_ps = p.ps != 0;
+  }
+}
+
+template <bool GEN>
+__device__ __forceinline__ float4 item_value(const Item<GEN>& it, bool ok, bool is_ps) {
+  float4 r;
+  if constexpr (!GEN) {
+    r = it.v;
+  } else {
+    r = is_ps ? make_float4(it.v.x * it.ku, it.v.z * it.kw, it.v.y * it.ku, it.v.w * it.kw)
+              : make_float4(it.v.x * it.ku, it.v.y * it.ku, it.v.z * it.ku, it.v.w * it.ku);
+  }
+  return ok ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+enum TileCfg { M32_TH8 = 0, M64_TH8, M128_TH4, M32_TH4, M64_TH4 };
+
+inline long long wg_count(const ConvArgs& a, int th, int mblk) {
+  return (long long)a.N * ((a.H + th - 1) / th) * ((a.W + 63) / 64) * ((a.nmblk + mblk - 1) / mblk);
+}
+
+// Tile choice: the biggest tile that still gives >= 2 workgroups per CU (256 CUs); below that,
+// shrink rows first (TH 8 -> 4), then the channel tile, so small feature maps still fill the chip.
+inline int choose_cfg(const ConvArgs& a) {
+  const long long want = 512;
+  if (a.nmblk >= 4) {
+    if (wg_count(a, 4, 4) >= want) return M128_TH4;
+    if (wg_count(a, 4, 2) >= want) return M64_TH4;
+    return M32_TH4;
+  }
+  if (a.nmblk >= 2) {
+    if (a.H >= 8 && wg_count(a, 8, 2) >= want) return M64_TH8;
+    if (wg_count(a, 4, 2) >= want) return M64_TH4;
+    return M32_TH4;
+  }
+  if (a.H >= 8 && wg_count(a, 8, 1) >= want) return M32_TH8;
+  return M32_TH4;
+}
+
+
+inline int fill_args(const slu_conv_desc* d, ConvArgs& a) {
+  if (!d || !d->out || !d->wpack || d->nsrc < 1 || d->nsrc > SLU_MAX_SRC) return SLU_EINVAL;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return SLU_EINVAL;
+  if (d->bn_a && !d->bn_b) return SLU_EINVAL;
+  int c = 0;
+  for (int s = 0; s < d->nsrc; ++s) {
+    const slu_conv_src& S = d->src[s];
+    if (!S.ptr || S.C <= 0) return SLU_EINVAL;
+    if (S.pixel_shuffle && ((S.C & 3) || (d->H & 1) || (d->W & 1))) return SLU_EINVAL;
+    a.src[s].ptr = S.ptr;
+    a.src[s].scale = S.scale;
+    a.src[s].C = S.C;
+    a.src[s].ps = S.pixel_shuffle ? 1 : 0;
+    a.src[s].cbeg = c;
+    a.src[s].ccount = S.pixel_shuffle ? S.C / 4 : S.C;
+    c += a.src[s].ccount;
+  }
+  if (c != d->Cin) return SLU_EINVAL;
+  if (d->precision != SLU_CONV_FP32 && d->precision != SLU_CONV_F16X3) return SLU_EINVAL;
+  if (d->ck != (d->precision == SLU_CONV_F16X3 ? 16 : slu_conv_ck(d->ksize))) return SLU_EINVAL;
+  a.nsrc = d->nsrc;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+  a.nchunks = (d->Cin + d->ck - 1) / d->ck;
+  a.nmblk = (d->Cout + 31) / 32;
+  a.wpack = d->wpack; a.bias = d->bias; a.bn_a = d->bn_a; a.bn_b = d->bn_b; a.resid = d->resid; a.out = d->out;
+  a.slope = d->slope; a.has_act = d->has_act;
+  a.vec = (d->W % 4 == 0);
+  a.gen = 0;
+  for (int s = 0; s < d->nsrc; ++s) {
+    if (reinterpret_cast<uintptr_t>(d->src[s].ptr) & 15) a.vec = 0;
+    if (d->src[s].pixel_shuffle || d->src[s].scale) a.gen = 1;
+  }
+  return SLU_OK;
+}
+
+
+}  // namespace slu_conv

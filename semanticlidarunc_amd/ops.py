@@ -72,6 +72,24 @@ def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_conv_weight_f16x3(weight: torch.Tensor) -> torch.Tensor:
+    """OIHW fp32 weight -> split-fp16 (hi, lo) MFMA A-fragment image for precision='f16x3'."""
+    _req(weight, "weight")
+    if weight.dim() != 4 or weight.shape[2] != weight.shape[3]:
+        raise RuntimeError(f"weight: expected [Cout,Cin,k,k], got {tuple(weight.shape)}")
+    lib = _lib.load()
+    cout, cin, ks, _ = weight.shape
+    n = lib.slu_packed_weight_bytes_f16x3(cout, cin, ks)
+    if n == 0:
+        raise RuntimeError("pack_conv_weight_f16x3: unsupported weight shape")
+    out = torch.empty(n, dtype=torch.uint8, device=weight.device)
+    check(lib.slu_pack_conv_weight_f16x3(weight.data_ptr(), cout, cin, ks, out.data_ptr(), _stream()), "slu_pack_conv_weight_f16x3")
+    return out
+
+
+PRECISIONS = {"fp32": 0, "f16x3": 1}
+
+
 def bn_fold(gamma, beta, mean, var, eps: float):
     """(a, b) with  a*x + b == eval BatchNorm(x)."""
     c = gamma.numel()
@@ -89,8 +107,12 @@ def bn_fold(gamma, beta, mean, var, eps: float):
 def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksize: int, dil: int, pad: int,
                  bias: Optional[torch.Tensor] = None, slope: Optional[float] = None,
                  bn_a: Optional[torch.Tensor] = None, bn_b: Optional[torch.Tensor] = None,
-                 resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = resid + bn_a * leaky(conv(cat(srcs)) + bias) + bn_b   (see slu_conv2d_fwd)."""
+                 resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                 precision: str = "fp32") -> torch.Tensor:
+    """out = resid + bn_a * leaky(conv(cat(srcs)) + bias) + bn_b   (see slu_conv2d_fwd).
+    precision 'fp32' (exact, wpack from pack_conv_weight) or 'f16x3' (split-fp16, wpack from pack_conv_weight_f16x3)."""
+    if precision not in PRECISIONS:
+        raise ValueError(f"unknown conv precision {precision!r}")
     lib = _lib.load()
     if not 1 <= len(srcs) <= _lib.MAX_SRC:
         raise RuntimeError(f"conv2d_fused: 1..{_lib.MAX_SRC} sources supported, got {len(srcs)}")
@@ -123,10 +145,16 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
         d.src[i].pixel_shuffle = 1 if s.pixel_shuffle else 0
         cin += contributed
         keep.append(t)
-    ck = lib.slu_conv_ck(ksize)
-    _req(wpack, "wpack")
-    if wpack.numel() != lib.slu_packed_weight_floats(cout, cin, ksize, ck):
-        raise RuntimeError(f"wpack: {wpack.numel()} floats does not match Cout={cout} Cin={cin} k={ksize}")
+    if precision == "f16x3":
+        ck = 16
+        _req(wpack, "wpack", torch.uint8)
+        if wpack.numel() != lib.slu_packed_weight_bytes_f16x3(cout, cin, ksize):
+            raise RuntimeError(f"wpack: {wpack.numel()} bytes does not match Cout={cout} Cin={cin} k={ksize} (f16x3)")
+    else:
+        ck = lib.slu_conv_ck(ksize)
+        _req(wpack, "wpack")
+        if wpack.numel() != lib.slu_packed_weight_floats(cout, cin, ksize, ck):
+            raise RuntimeError(f"wpack: {wpack.numel()} floats does not match Cout={cout} Cin={cin} k={ksize}")
     for t, nme in ((bias, "bias"), (bn_a, "bn_a"), (bn_b, "bn_b")):
         if t is not None:
             _req(t, nme)
@@ -150,6 +178,7 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
     d.wpack, d.bias = wpack.data_ptr(), _ptr(bias)
     d.has_act, d.slope = (0, 0.0) if slope is None else (1, float(slope))
     d.bn_a, d.bn_b, d.resid, d.out = _ptr(bn_a), _ptr(bn_b), _ptr(resid), out.data_ptr()
+    d.precision = PRECISIONS[precision]
     if TIMING is None:
         check(lib.slu_conv2d_fwd(C.byref(d), _stream()), "slu_conv2d_fwd")
         return out

@@ -15,6 +15,7 @@ dropout draws), so torch's RNG stream and the ``.training`` flags behave as in t
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -26,16 +27,33 @@ from .ops import ConvSource
 
 _SLOPE = 0.01  # nn.LeakyReLU() default used throughout the reference model
 
+# Multiply precision of the fused inference convs: "fp32" = exact fp32 MFMA; "f16x3" = split-fp16 (three f16
+# MFMAs per K-step, ~2^-22 relative product error, 5x fewer matrix-core cycles).  Training / autograd always
+# runs the exact kernels.  Override per process with SLU_CONV_PRECISION or set_conv_precision().
+_CONV_PRECISION = os.environ.get("SLU_CONV_PRECISION", "fp32")
+
+
+def set_conv_precision(precision: str) -> None:
+    global _CONV_PRECISION
+    if precision not in ops.PRECISIONS:
+        raise ValueError(f"unknown conv precision {precision!r}; choose from {sorted(ops.PRECISIONS)}")
+    _CONV_PRECISION = precision
+
+
+def get_conv_precision() -> str:
+    return _CONV_PRECISION
+
 
 class _Prepared:
     """Device-side derived constants of one conv (+ its BatchNorm): the MFMA-ordered weight image and
     the folded BN affine.  Rebuilt lazily whenever the owning parameters/buffers change."""
 
-    __slots__ = ("key", "wpack", "bn_key", "bn_a", "bn_b", "dgrad")
+    __slots__ = ("key", "wpack", "bn_key", "bn_a", "bn_b", "dgrad", "key16", "wpack16")
 
     def __init__(self):
         self.key = self.bn_key = None
         self.wpack = self.bn_a = self.bn_b = None
+        self.key16 = self.wpack16 = None
         self.dgrad = {}          # packed data-gradient weights, keyed by the weight version
 
 
@@ -74,9 +92,16 @@ class _FusedBlock(nn.Module):
                 p.bn_a, p.bn_b = ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
                 p.bn_key = bkey
             bn_a, bn_b = p.bn_a, p.bn_b
-        return ops.conv2d_fused(srcs, p.wpack, conv.out_channels, k, conv.dilation[0], conv.padding[0],
+        wpack, precision = p.wpack, "fp32"
+        if _CONV_PRECISION == "f16x3" and k > 1:      # 1x1 convs are HBM-bound: the exact kernel is as fast there
+            precision = "f16x3"
+            if p.key16 != wkey:
+                p.wpack16 = ops.pack_conv_weight_f16x3(conv.weight.detach().contiguous())
+                p.key16 = wkey
+            wpack = p.wpack16
+        return ops.conv2d_fused(srcs, wpack, conv.out_channels, k, conv.dilation[0], conv.padding[0],
                                 bias=None if conv.bias is None else conv.bias.detach(),
-                                slope=slope, bn_a=bn_a, bn_b=bn_b, resid=resid)
+                                slope=slope, bn_a=bn_a, bn_b=bn_b, resid=resid, precision=precision)
 
 
 def _draw(drop: nn.Dropout2d, n: int, c: int, device, override: Optional[Dict[str, torch.Tensor]], name: str):
