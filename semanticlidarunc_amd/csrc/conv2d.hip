@@ -279,7 +279,10 @@ extern "C" int slu_conv2d_kernel_name(const slu_conv_desc* d, char* buf, size_t 
   const int rc = fill_args(d, a);
   if (rc != SLU_OK) return rc;
   static const int kTile[5][4] = {{1, 1, 4, 2}, {2, 1, 4, 2}, {2, 2, 2, 2}, {1, 1, 4, 1}, {2, 1, 4, 1}};
-  const int* t = kTile[choose_cfg(a)];
+  int cfg = choose_cfg(a);
+  if (d->precision == SLU_CONV_F16X3 && cfg == M32_TH8) cfg = M32_TH4;
+  if (d->precision == SLU_CONV_F16X3 && cfg == M64_TH8) cfg = M64_TH4;
+  const int* t = kTile[cfg];
   if (d->precision == SLU_CONV_F16X3)
     snprintf(buf, buflen, "conv_f16x3_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", d->ksize, d->dil, d->pad, t[0], t[1], t[2], t[3], a.gen ? "true" : "false");
   else

@@ -22,16 +22,19 @@ namespace {
 
 constexpr int CK16 = 16;
 
+// x = hi + lo with hi = fp16(x) rounded toward zero (v_cvt_pkrtz_f16_f32 converts two values per instruction)
+// and lo = fp16(x - hi): 3 VALU per element; hi carries 11 bits, lo at least 10 more.
 __device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo) {
-  half8 h, l;
+  unsigned h[4], l[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const _Float16 a = (_Float16)x[k];
-    h[k] = a;
-    l[k] = (_Float16)(x[k] - (float)a);
+  for (int k = 0; k < 4; ++k) {
+    const auto a = __builtin_amdgcn_cvt_pkrtz(x[2 * k], x[2 * k + 1]);
+    const auto b = __builtin_amdgcn_cvt_pkrtz(x[2 * k] - (float)a[0], x[2 * k + 1] - (float)a[1]);
+    h[k] = __builtin_bit_cast(unsigned, a);
+    l[k] = __builtin_bit_cast(unsigned, b);
   }
-  hi = __builtin_bit_cast(uint4, h);
-  lo = __builtin_bit_cast(uint4, l);
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool GEN>
@@ -42,7 +45,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
   constexpr int TW = 64, TH = WN * RPW, NB = 2 * RPW;
   constexpr int XO = PAD ? 4 : 0;
   constexpr int LW = TW + 2 * XO, LH = TH + 2 * PAD, LW4 = LW / 4;
-  constexpr int REC = LH * LW;                      // 16-byte records per 8-channel group
+  constexpr int LWP = LW + LW / 8;                  // one pad record after every 8: quads of neighbouring lanes start 64,80,64,80..
+                                                    // bytes apart, so the 8 lanes of a ds_write_b128 group hit distinct banks
+  constexpr int REC = LH * LWP;                     // 16-byte record slots per 8-channel group
   constexpr int MBLK = WM * MB;
   constexpr int NITEM = 2 * LH * LW4, NI = (NITEM + NT - 1) / NT;       // (group, row, 4-pixel quad) items
   constexpr int NWV = MBLK * T * 128, NW = (NWV + NT - 1) / NT;          // uint4 items of the weight tile
@@ -85,9 +90,60 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
   }
 
   const int hh = lane >> 5, jj = lane & 31;
-  const int bbase = hh * REC + (wn * RPW) * LW + jj + (XO - PAD);
+  int bcol[KS];                                     // padded slot of (first column + lane + tap shift), per horizontal tap
+#pragma unroll
+  for (int tj = 0; tj < KS; ++tj) {
+    const int c = (XO - PAD) + jj + tj * DIL;
+    bcol[tj] = hh * REC + (wn * RPW) * LWP + c + (c >> 3);
+  }
   const int abase = (wm * MB) * T * 64 + lane;
   const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpack);
+
+  // The raw fp32 tile of chunk q+1 is fetched into registers (all loads of a thread back to back) before the
+  // MFMA phase of chunk q and converted / written to LDS after the barrier that retires chunk q's LDS reads,
+  // so HBM latency overlaps the matrix-core phase.
+  Item<GEN> st[NI][8];
+  unsigned okm[NI], psm[NI];
+  auto fetch_tile = [&](int q, int tq) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int e = tq + i * NT;
+      const int g2 = e / (LH * LW4);
+      const int rem = e - g2 * (LH * LW4);
+      const int r = rem / LW4;
+      const int c4 = rem - r * LW4;
+      const int gy = y0 + r - PAD, gx4 = x0 - XO + 4 * c4;
+      const bool pix_ok = (NITEM % NT == 0 || e < NITEM) && gy >= 0 && gy < a.H && gx4 >= 0 && gx4 < a.W;
+      okm[i] = 0; psm[i] = 0;
+      bool fast = false;
+      if constexpr (!GEN) {
+        // common case: the 8 channels of this item are 8 consecutive channels of ONE plain source and the quad is
+        // inside the image: one base address, constant channel stride, no per-channel selects
+        const int cg0 = q * CK16 + g2 * 8;
+        const SrcPick p0 = pick_src(a, (pix_ok && cg0 < a.Cin) ? cg0 : 0);
+        fast = pix_ok && cg0 + 8 <= a.Cin && p0.cl + 8 <= p0.C;
+        if (fast) {
+          const size_t cs = (size_t)a.H * a.W;
+          const float* bp = p0.ptr + (((size_t)n * p0.C + p0.cl) * a.H + gy) * a.W + gx4;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) st[i][k].v = *reinterpret_cast<const float4*>(bp + k * cs);
+          okm[i] = 0xFFu;
+        }
+      }
+      if (!fast) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int cg = q * CK16 + g2 * 8 + k;
+          const bool ok = pix_ok && cg < a.Cin;
+          bool ps;
+          fetch_item<GEN>(a, n, ok ? cg : 0, gy, gx4, ok, st[i][k], ps);
+          okm[i] |= (ok ? 1u : 0u) << k;
+          psm[i] |= (ps ? 1u : 0u) << k;
+        }
+      }
+    }
+  };
+  if (a.vec) fetch_tile(0, tid);
 
   for (int q = 0; q < a.nchunks; ++q) {
     __syncthreads();
@@ -107,28 +163,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
     }
     // ---- input tile: 16 channels, converted to (hi, lo) fp16 and transposed to channel-innermost ----
     if (a.vec) {
-      Item<GEN> st[NI][8];
-      unsigned okm[NI], psm[NI];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int e = tq + i * NT;
-        const int g2 = e / (LH * LW4);
-        const int rem = e - g2 * (LH * LW4);
-        const int r = rem / LW4;
-        const int c4 = rem - r * LW4;
-        const int gy = y0 + r - PAD, gx4 = x0 - XO + 4 * c4;
-        const bool pix_ok = (NITEM % NT == 0 || e < NITEM) && gy >= 0 && gy < a.H && gx4 >= 0 && gx4 < a.W;
-        okm[i] = 0; psm[i] = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int cg = q * CK16 + g2 * 8 + k;
-          const bool ok = pix_ok && cg < a.Cin;
-          bool ps;
-          fetch_item<GEN>(a, n, ok ? cg : 0, gy, gx4, ok, st[i][k], ps);
-          okm[i] |= (ok ? 1u : 0u) << k;
-          psm[i] |= (ps ? 1u : 0u) << k;
-        }
-      }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int e = tq + i * NT;
@@ -138,13 +172,21 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
           const int r = rem / LW4;
           const int c4 = rem - r * LW4;
           float4 v[8];
+          if constexpr (!GEN) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = item_value<GEN>(st[i][k], (okm[i] >> k) & 1u, (psm[i] >> k) & 1u);
-          const int rec0 = g2 * REC + r * LW + 4 * c4;
-          const int rot = (c4 >> 1) & 3;            // rotated pixel order: the 8 lanes of a b128 write group hit distinct banks
+            for (int k = 0; k < 8; ++k) v[k] = st[i][k].v;
+            if (okm[i] != 0xFFu) {          // border / channel tail: zero what lies outside
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int p = (s + rot) & 3;
+              for (int k = 0; k < 8; ++k)
+                if (!((okm[i] >> k) & 1u)) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = item_value<GEN>(st[i][k], (okm[i] >> k) & 1u, (psm[i] >> k) & 1u);
+          }
+          const int rec0 = g2 * REC + r * LWP + 4 * c4 + (c4 >> 1);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
             float x[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] = p == 0 ? v[k].x : (p == 1 ? v[k].y : (p == 2 ? v[k].z : v[k].w));
@@ -156,9 +198,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
         }
       }
     } else {   // any W: element-wise (slow path, odd test shapes only)
-      for (int e = tq; e < 2 * REC; e += NT) {
-        const int g2 = e / REC;
-        const int rem = e - g2 * REC;
+      for (int e = tq; e < 2 * LH * LW; e += NT) {
+        const int g2 = e / (LH * LW);
+        const int rem = e - g2 * (LH * LW);
         const int r = rem / LW;
         const int c = rem - r * LW;
         const int gy = y0 + r - PAD, gx = x0 + c - XO;
@@ -170,8 +212,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
         }
         uint4 hi, lo;
         split8(x, hi, lo);
-        s_bh[e] = hi;
-        s_bl[e] = lo;
+        s_bh[g2 * REC + r * LWP + c + (c >> 3)] = hi;
+        s_bl[g2 * REC + r * LWP + c + (c >> 3)] = lo;
       }
     }
 #pragma unroll
@@ -185,10 +227,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
       }
     }
     __syncthreads();
+    if (a.vec && q + 1 < a.nchunks) fetch_tile(q + 1, tq);     // in flight during the MFMA phase below
     // ---- one K=16 step per tap: 3 MFMAs per (channel block, pixel block) ----
 #pragma unroll
     for (int tap = 0; tap < T; ++tap) {
-      const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
+      const int dy = (tap / KS) * DIL;
       half8 ah[MB], al[MB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
@@ -198,7 +241,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const int rr = b >> 1, cb = b & 1;
-        const int idx = bbase + (rr + dy) * LW + cb * 32 + dx;
+        const int idx = bcol[tap % KS] + (rr + dy) * LWP + cb * 36;
         const half8 bh = __builtin_bit_cast(half8, s_bh[idx]);
         const half8 bl = __builtin_bit_cast(half8, s_bl[idx]);
 #pragma unroll
@@ -265,7 +308,7 @@ __global__ void pack_f16x3_kernel(const float* __restrict__ w, int cout, int cin
 template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool GEN>
 int launch_cfg16(ConvArgs& a, hipStream_t st) {
   constexpr int TH = WN * RPW, MBLK = WM * MB, T = KS * KS, XO = PAD ? 4 : 0;
-  constexpr int REC = (TH + 2 * PAD) * (64 + 2 * XO);
+  constexpr int REC = (TH + 2 * PAD) * ((64 + 2 * XO) + (64 + 2 * XO) / 8);
   constexpr size_t lds = (size_t)4 * REC * 16 + (size_t)2 * MBLK * T * 64 * 16 + (size_t)3 * MBLK * 32 * 4;
   static_assert(lds <= 160 * 1024, "LDS budget");
   a.tiles_x = (a.W + 63) / 64;
@@ -326,7 +369,10 @@ int slu_conv2d_fwd_f16x3_impl(const slu_conv_desc* d, hipStream_t st) {
   ConvArgs a{};
   const int rc = fill_args(d, a);
   if (rc != SLU_OK) return rc;
-  const int cfg = choose_cfg(a);
+  int cfg = choose_cfg(a);
+  // 4-row tiles only: the (hi, lo) input tile of an 8-row tile leaves room for a single workgroup per CU
+  if (cfg == M32_TH8) cfg = M32_TH4;
+  if (cfg == M64_TH8) cfg = M64_TH4;
   if (d->ksize == 1 && d->dil == 1 && d->pad == 0) return launch_family16<1, 1, 0>(a, cfg, st);
   if (d->ksize == 3 && d->dil == 1 && d->pad == 1) return launch_family16<3, 1, 1>(a, cfg, st);
   if (d->ksize == 3 && d->dil == 2 && d->pad == 2) return launch_family16<3, 2, 2>(a, cfg, st);
