@@ -279,6 +279,185 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 1x1 convolution, streaming form.  No halo => no LDS input tile: a wave owns NBW blocks of 32 consecutive pixels
+// and ALL output channels (MB blocks of 32), reads its B operand straight from global memory (lane (r, h): 8 channels
+// of pixel r, eight 4-byte loads that are each two 128-byte segments per wave), converts to (hi, lo) in registers
+// and runs 3 MFMAs per channel block.  The input is read from HBM exactly once, the output written once; only
+// the weight fragments (shared by the 4 waves) go through LDS, 64 input channels per barrier pair.
+// Requirements (else the tiled kernel is used): plain sources whose channel counts are multiples of 16 (the last
+// one may be ragged), H*W % 32 == 0.
+// ---------------------------------------------------------------------------------------------------------
+template <int MB, int NBW>
+__global__ __launch_bounds__(256, (MB * NBW >= 8) ? 1 : 2) void conv1x1_f16x3_kernel(const ConvArgs a, const float* __restrict__ resid,
+                                                                                      float* __restrict__ out) {
+  constexpr int KSPC = 4;                               // K-steps (16 channels each) per weight chunk
+  constexpr int NWV = MB * KSPC * 128, NW = (NWV + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* s_ah = reinterpret_cast<uint4*>(smem);         // [MB][KSPC][64]
+  uint4* s_al = s_ah + MB * KSPC * 64;
+  float* s_epi = reinterpret_cast<float*>(s_al + MB * KSPC * 64);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, jj = lane & 31;
+  const long long HW = (long long)a.H * a.W;
+  const long long nblocks = (long long)a.N * HW / 32;
+  const long long pb0 = ((long long)blockIdx.x * 4 + wave) * NBW;
+
+  if (tid < MB * 32) {
+    const bool ok = tid < a.Cout;
+    s_epi[tid] = (ok && a.bias) ? a.bias[tid] : 0.0f;
+    s_epi[MB * 32 + tid] = (ok && a.bn_a) ? a.bn_a[tid] : 1.0f;
+    s_epi[2 * MB * 32 + tid] = (ok && a.bn_a) ? a.bn_b[tid] : 0.0f;
+  }
+
+  f32x16 acc[MB][NBW];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
+
+  // per pixel block: image index and offset inside the H*W plane of this lane's pixel
+  long long img[NBW];
+  long long hw[NBW];
+  bool live[NBW];
+#pragma unroll
+  for (int b = 0; b < NBW; ++b) {
+    const long long pb = pb0 + b;
+    live[b] = pb < nblocks;
+    const long long pix = (live[b] ? pb : 0) * 32 + jj;
+    img[b] = pix / HW;
+    hw[b] = pix - img[b] * HW;
+  }
+
+  const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpack);
+  const int nq = (a.nchunks + KSPC - 1) / KSPC;         // a.nchunks counts 16-channel groups
+  int src = 0;                                          // source that holds channel group `g16` (sources are 16-aligned)
+  for (int q = 0; q < nq; ++q) {
+    // ---- B operands of the whole chunk: issued before the barriers so HBM latency overlaps the weight staging ----
+    float x[KSPC][NBW][8];
+    {
+      int s_ = src;
+#pragma unroll
+      for (int ks = 0; ks < KSPC; ++ks) {
+        const int c0 = (q * KSPC + ks) * CK16;          // first channel of this K-step (wave-uniform)
+        while (s_ + 1 < a.nsrc && c0 >= a.src[s_ + 1].cbeg) ++s_;
+        const SrcDev& S = a.src[s_];
+        const int cl0 = c0 - S.cbeg + 8 * hh;           // this lane half's first channel inside the source
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+          const size_t base = ((size_t)img[b] * S.C + cl0) * HW + hw[b];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            // channels past the end of the source (ragged tail / K padding): read element 0 instead, use 0
+            const bool ok = live[b] && c0 < a.Cin && cl0 + k < S.C;
+            const float v = S.ptr[ok ? base + (size_t)k * HW : 0];
+            x[ks][b][k] = ok ? v : 0.0f;
+          }
+        }
+      }
+      src = s_;
+    }
+    __syncthreads();
+    uint4 sw[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int e = tid + i * 256;
+      const int m = e / (KSPC * 128);
+      const int r = e - m * (KSPC * 128);
+      const int ks = r >> 7;
+      const bool ok = (NWV % 256 == 0 || e < NWV) && m < a.nmblk && q * KSPC + ks < a.nchunks;
+      const size_t off = ok ? ((size_t)m * a.nchunks + q * KSPC + ks) * 128 + (r & 127) : 0;
+      sw[i] = wsrc[off];
+      if (!ok) sw[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int e = tid + i * 256;
+      if (NWV % 256 == 0 || e < NWV) {
+        const int m = e / (KSPC * 128);
+        const int r = e - m * (KSPC * 128);
+        const int ks = r >> 7, hl = (r >> 6) & 1, ln = r & 63;
+        (hl ? s_al : s_ah)[(m * KSPC + ks) * 64 + ln] = sw[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KSPC; ++ks) {
+      half8 bh[NBW], bl[NBW];
+#pragma unroll
+      for (int b = 0; b < NBW; ++b) {
+        uint4 hi, lo;
+        split8(x[ks][b], hi, lo);
+        bh[b] = __builtin_bit_cast(half8, hi);
+        bl[b] = __builtin_bit_cast(half8, lo);
+      }
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const half8 ah = __builtin_bit_cast(half8, s_ah[(i * KSPC + ks) * 64 + lane]);
+        const half8 al = __builtin_bit_cast(half8, s_al[(i * KSPC + ks) * 64 + lane]);
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+          acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[b], acc[i][b], 0, 0, 0);
+          acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b], acc[i][b], 0, 0, 0);
+          acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b], acc[i][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const bool ok = live[b] && co < a.Cout;
+        const size_t o = ok ? ((size_t)img[b] * a.Cout + co) * HW + hw[b] : 0;
+        float v = acc[i][b][r] + s_epi[co];
+        if (a.has_act) v = v > 0.0f ? v : v * a.slope;
+        v = v * s_epi[MB * 32 + co] + s_epi[2 * MB * 32 + co];
+        if (resid) v += resid[o];
+        if (ok) out[o] = v;
+      }
+}
+
+template <int MB, int NBW>
+int launch_1x1(ConvArgs& a, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * MB * 4 * 64 * 16 + (size_t)3 * MB * 32 * 4;
+  const long long nblocks = (long long)a.N * a.H * a.W / 32;
+  const long long gx = (nblocks + 4 * NBW - 1) / (4 * NBW);
+  if (gx <= 0 || gx > 0x7fffffffLL) return SLU_EUNSUPPORTED;
+  auto kern = conv1x1_f16x3_kernel<MB, NBW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SLU_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, a, a.resid, a.out);
+  SLU_CHECK_LAUNCH();
+}
+
+// the streaming kernel applies when every source is plain and 16-channel aligned and pixel blocks do not straddle images
+bool stream_1x1_ok(const slu_conv_desc* d, const ConvArgs& a) {
+  if (d->ksize != 1 || a.gen || a.nmblk > 8) return false;
+  if (((long long)a.H * a.W) % 32) return false;
+  for (int s = 0; s + 1 < a.nsrc; ++s)
+    if (a.src[s].ccount % 16) return false;
+  return true;
+}
+
+int launch_1x1_any(ConvArgs& a, hipStream_t st) {
+  if (a.nmblk == 1) return launch_1x1<1, 2>(a, st);
+  if (a.nmblk == 2) return launch_1x1<2, 2>(a, st);
+  if (a.nmblk <= 4) return launch_1x1<4, 2>(a, st);
+  return launch_1x1<8, 1>(a, st);
+}
+
 // wpack16[mblk][chunk][tap][hi|lo][lane][8]: lane (r, h) holds W[co = 32 mblk + r][ci = 16 chunk + 8 h + j][tap], j = 0..7
 __global__ void pack_f16x3_kernel(const float* __restrict__ w, int cout, int cin, int ks, int nchunks, size_t total_frag,
                                   uint4* __restrict__ out) {
@@ -369,6 +548,7 @@ int slu_conv2d_fwd_f16x3_impl(const slu_conv_desc* d, hipStream_t st) {
   ConvArgs a{};
   const int rc = fill_args(d, a);
   if (rc != SLU_OK) return rc;
+  if (stream_1x1_ok(d, a)) return launch_1x1_any(a, st);
   int cfg = choose_cfg(a);
   // 4-row tiles only: the (hi, lo) input tile of an 8-row tile leaves room for a single workgroup per CU
   if (cfg == M32_TH8) cfg = M32_TH4;

@@ -93,7 +93,7 @@ class _FusedBlock(nn.Module):
                 p.bn_key = bkey
             bn_a, bn_b = p.bn_a, p.bn_b
         wpack, precision = p.wpack, "fp32"
-        if _CONV_PRECISION == "f16x3" and k > 1:      # 1x1 convs are HBM-bound: the exact kernel is as fast there
+        if _CONV_PRECISION == "f16x3":
             precision = "f16x3"
             if p.key16 != wkey:
                 p.wpack16 = ops.pack_conv_weight_f16x3(conv.weight.detach().contiguous())
