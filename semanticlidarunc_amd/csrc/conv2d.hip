@@ -286,7 +286,7 @@ extern "C" int slu_conv2d_kernel_name(const slu_conv_desc* d, char* buf, size_t 
   if (d->precision == SLU_CONV_F16X3 && d->ksize == 1 && !a.gen && a.nmblk <= 8 && ((long long)a.H * a.W) % 32 == 0 &&
       (a.nsrc < 2 || a.src[0].ccount % 16 == 0) && (a.nsrc < 3 || a.src[1].ccount % 16 == 0)) {
     const int mb = a.nmblk == 1 ? 1 : (a.nmblk == 2 ? 2 : (a.nmblk <= 4 ? 4 : 8));
-    snprintf(buf, buflen, "conv1x1_f16x3_kernel<%d, %d>", mb, mb == 8 ? 1 : 2);
+    snprintf(buf, buflen, "conv1x1_f16x3_kernel<%d, %d>", mb, 1);
     return SLU_OK;
   }
   if (d->precision == SLU_CONV_F16X3)

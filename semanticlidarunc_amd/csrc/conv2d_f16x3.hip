@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
 // one may be ragged), H*W % 32 == 0.
 // ---------------------------------------------------------------------------------------------------------
 template <int MB, int NBW>
-__global__ __launch_bounds__(256, (MB * NBW >= 8) ? 1 : 2) void conv1x1_f16x3_kernel(const ConvArgs a, const float* __restrict__ resid,
+__global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4)) void conv1x1_f16x3_kernel(const ConvArgs a, const float* __restrict__ resid,
                                                                                       float* __restrict__ out) {
   constexpr int KSPC = 4;                               // K-steps (16 channels each) per weight chunk
   constexpr int NWV = MB * KSPC * 128, NW = (NWV + 255) / 256;
@@ -452,9 +452,9 @@ bool stream_1x1_ok(const slu_conv_desc* d, const ConvArgs& a) {
 }
 
 int launch_1x1_any(ConvArgs& a, hipStream_t st) {
-  if (a.nmblk == 1) return launch_1x1<1, 2>(a, st);
-  if (a.nmblk == 2) return launch_1x1<2, 2>(a, st);
-  if (a.nmblk <= 4) return launch_1x1<4, 2>(a, st);
+  if (a.nmblk == 1) return launch_1x1<1, 1>(a, st);
+  if (a.nmblk == 2) return launch_1x1<2, 1>(a, st);
+  if (a.nmblk <= 4) return launch_1x1<4, 1>(a, st);
   return launch_1x1<8, 1>(a, st);
 }
 
