@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 2
+#define SLU_ABI_VERSION 3
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -56,6 +56,9 @@ typedef struct slu_conv_src {
   const float* scale;  /* [N, C] multiplier per (sample, source channel), or NULL               */
   int32_t C;           /* channels of the stored tensor                                          */
   int32_t pixel_shuffle; /* 1: contributes C/4 channels, in[c,y,x] = ptr[4c+2(y&1)+(x&1), y/2, x/2] */
+  int32_t nbatch;      /* 0: the tensor holds N images; k > 0: it holds k images and output image n reads image n % k
+                          (a deterministic skip tensor shared by the stacked MC passes); `scale` stays [N, C]      */
+  int32_t reserved_;
 } slu_conv_src;
 
 typedef struct slu_conv_desc {   /* HOST struct */
@@ -105,6 +108,9 @@ int slu_bn_fold(const float* gamma, const float* beta, const float* mean, const 
  * x [N,C,H,W] -> y [N,C,(H+1)/2,(W+1)/2]; scale [N,C] or NULL. */
 int slu_avgpool3s2_fwd(const float* x, const float* scale, float* y, int N, int C, int H, int W,
                        slu_stream_t stream);
+/* same, but x holds only `in_batch` images and output image n pools x[n % in_batch] (scale is [N,C]) */
+int slu_avgpool3s2_bcast_fwd(const float* x, const float* scale, float* y, int N, int in_batch, int C, int H, int W,
+                             slu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * MC-dropout reduction (replaces models/trainer.py:1105-1136,1143-1154 = tester.py:412-451)

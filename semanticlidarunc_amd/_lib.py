@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -21,7 +21,8 @@ c_stream = C.c_void_p
 
 
 class ConvSrc(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("C", C.c_int32), ("pixel_shuffle", C.c_int32)]
+    _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("C", C.c_int32), ("pixel_shuffle", C.c_int32),
+                ("nbatch", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -53,6 +54,7 @@ SIGNATURES = {
     "slu_conv2d_kernel_name": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, C.c_size_t]),
     "slu_bn_fold": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_int, c_f32p, c_f32p, c_stream]),
     "slu_avgpool3s2_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_avgpool3s2_bcast_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_mc_reduce": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_f32p, c_f32p,
                                 c_i64p, c_stream]),
     "slu_softmax_entropy": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_f32p, c_i64p,

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
         fast = pix_ok && cg0 + 8 <= a.Cin && p0.cl + 8 <= p0.C;
         if (fast) {
           const size_t cs = (size_t)a.H * a.W;
-          const float* bp = p0.ptr + (((size_t)n * p0.C + p0.cl) * a.H + gy) * a.W + gx4;
+          const int ns = p0.nb ? n % p0.nb : n;
+          const float* bp = p0.ptr + (((size_t)ns * p0.C + p0.cl) * a.H + gy) * a.W + gx4;
 #pragma unroll
           for (int k = 0; k < 8; ++k) st[i][k].v = *reinterpret_cast<const float4*>(bp + k * cs);
           okm[i] = 0xFFu;
@@ -348,7 +349,8 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
         const int cl0 = c0 - S.cbeg + 8 * hh;           // this lane half's first channel inside the source
 #pragma unroll
         for (int b = 0; b < NBW; ++b) {
-          const size_t base = ((size_t)img[b] * S.C + cl0) * HW + hw[b];
+          const long long is_ = S.nb ? img[b] % S.nb : img[b];
+          const size_t base = ((size_t)is_ * S.C + cl0) * HW + hw[b];
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             // channels past the end of the source (ragged tail / K padding): read element 0 instead, use 0

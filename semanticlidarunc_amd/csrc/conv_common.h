@@ -16,6 +16,7 @@ struct SrcDev {
   int ps;      // pixel-shuffle source
   int cbeg;    // first conv-input channel contributed
   int ccount;  // number of conv-input channels contributed
+  int nb;      // images held by the tensor (output image n reads image n % nb); 0 = N
 };
 
 struct ConvArgs {
@@ -39,27 +40,28 @@ struct ConvArgs {
 struct SrcPick {
   const float* ptr;
   const float* scale;
-  int C, cl, ps;
+  int C, cl, ps, nb;
 };
 __device__ __forceinline__ SrcPick pick_src(const ConvArgs& a, int cg) {
-  SrcPick p{a.src[0].ptr, a.src[0].scale, a.src[0].C, cg, a.src[0].ps};
+  SrcPick p{a.src[0].ptr, a.src[0].scale, a.src[0].C, cg, a.src[0].ps, a.src[0].nb};
 #pragma unroll
   for (int s = 1; s < SLU_MAX_SRC; ++s)
-    if (s < a.nsrc && cg >= a.src[s].cbeg) p = SrcPick{a.src[s].ptr, a.src[s].scale, a.src[s].C, cg - a.src[s].cbeg, a.src[s].ps};
+    if (s < a.nsrc && cg >= a.src[s].cbeg) p = SrcPick{a.src[s].ptr, a.src[s].scale, a.src[s].C, cg - a.src[s].cbeg, a.src[s].ps, a.src[s].nb};
   return p;
 }
 
 // one element (any W): used only when W % 4 != 0
 __device__ __forceinline__ float load_input(const ConvArgs& a, int n, int cg, int gy, int gx) {
   const SrcPick p = pick_src(a, cg);
+  const int ns = p.nb ? n % p.nb : n;           // image of the source tensor
   float v;
   int cs;
   if (!p.ps) {
     cs = p.cl;
-    v = p.ptr[(((size_t)n * p.C + cs) * a.H + gy) * a.W + gx];
+    v = p.ptr[(((size_t)ns * p.C + cs) * a.H + gy) * a.W + gx];
   } else {
     cs = p.cl * 4 + ((gy & 1) << 1) + (gx & 1);
-    v = p.ptr[(((size_t)n * p.C + cs) * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)];
+    v = p.ptr[(((size_t)ns * p.C + cs) * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)];
   }
   if (p.scale) v *= p.scale[(size_t)n * p.C + cs];
   return v;
@@ -83,15 +85,17 @@ struct Item<true> {
 template <bool GEN>
 __device__ __forceinline__ void fetch_item(const ConvArgs& a, int n, int cg, int gy, int gx4, bool ok, Item<GEN>& it, bool& is_ps) {
   const SrcPick p = pick_src(a, cg);
+  const int ns = p.nb ? n % p.nb : n;           // image of the source tensor (multipliers stay per output image)
   if constexpr (!GEN) {
-    const size_t idx = ok ? (((size_t)n * p.C + p.cl) * a.H + gy) * a.W + gx4 : 0;
+    const size_t idx = ok ? (((size_t)ns * p.C + p.cl) * a.H + gy) * a.W + gx4 : 0;
     it.v = *reinterpret_cast<const float4*>(p.ptr + idx);
     is_ps = false;
   } else {
     const size_t hp = (size_t)(a.H >> 1) * (a.W >> 1);
     const int cs = p.ps ? p.cl * 4 + ((gy & 1) << 1) : p.cl;
-    const size_t base = ((size_t)n * p.C + cs);
-    size_t i0 = p.ps ? base * hp + (size_t)(gy >> 1) * (a.W >> 1) + (gx4 >> 1) : (base * a.H + gy) * a.W + gx4;
+    const size_t base = ((size_t)n * p.C + cs);          // multiplier index
+    const size_t dbase = ((size_t)ns * p.C + cs);        // data index
+    size_t i0 = p.ps ? dbase * hp + (size_t)(gy >> 1) * (a.W >> 1) + (gx4 >> 1) : (dbase * a.H + gy) * a.W + gx4;
     size_t i1 = p.ps ? i0 + hp : i0 + 2;      // second 8-byte half: next stored channel / next two pixels
     if (!ok) { i0 = 0; i1 = 0; }
     const float2 u = *reinterpret_cast<const float2*>(p.ptr + i0);
@@ -159,6 +163,7 @@ inline int fill_args(const slu_conv_desc* d, ConvArgs& a) {
     a.src[s].ps = S.pixel_shuffle ? 1 : 0;
     a.src[s].cbeg = c;
     a.src[s].ccount = S.pixel_shuffle ? S.C / 4 : S.C;
+    a.src[s].nb = S.nbatch > 0 ? S.nbatch : 0;
     c += a.src[s].ccount;
   }
   if (c != d->Cin) return SLU_EINVAL;

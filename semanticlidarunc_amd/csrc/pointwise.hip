@@ -20,7 +20,7 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 
 // y[n,c,oy,ox] = (1/9) sum_{i,j in -1..1} s * x[n,c,2oy+i,2ox+j]  (zeros outside; divisor always 9)
 __global__ void avgpool3s2_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ y,
-                                  int NC, int H, int W, int OH, int OW) {
+                                  int NC, int H, int W, int OH, int OW, int C, int in_batch) {
   const size_t total = (size_t)NC * OH * OW;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int ox = (int)(e % OW);
@@ -28,7 +28,8 @@ __global__ void avgpool3s2_kernel(const float* __restrict__ x, const float* __re
     const int oy = (int)(r % OH);
     const size_t nc = r / OH;
     const float s = scale ? scale[nc] : 1.0f;
-    const float* p = x + nc * (size_t)H * W;
+    const size_t nc_in = in_batch ? ((nc / C) % in_batch) * C + nc % C : nc;   // broadcast source image
+    const float* p = x + nc_in * (size_t)H * W;
     float acc = 0.0f;
 #pragma unroll
     for (int i = -1; i <= 1; ++i) {
@@ -153,7 +154,18 @@ extern "C" int slu_avgpool3s2_fwd(const float* x, const float* scale, float* y, 
   const size_t total = (size_t)N * C * OH * OW;
   const size_t nb = (total + 255) / 256;
   hipLaunchKernelGGL(avgpool3s2_kernel, dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, slu_stream(stream), x, scale, y,
-                     N * C, H, W, OH, OW);
+                     N * C, H, W, OH, OW, C, 0);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_avgpool3s2_bcast_fwd(const float* x, const float* scale, float* y, int N, int in_batch, int C, int H, int W,
+                                        slu_stream_t stream) {
+  if (!x || !y || N <= 0 || in_batch <= 0 || C <= 0 || H <= 0 || W <= 0) return SLU_EINVAL;
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const size_t total = (size_t)N * C * OH * OW;
+  const size_t nb = (total + 255) / 256;
+  hipLaunchKernelGGL(avgpool3s2_kernel, dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, slu_stream(stream), x, scale, y,
+                     N * C, H, W, OH, OW, C, in_batch);
   SLU_CHECK_LAUNCH();
 }
 

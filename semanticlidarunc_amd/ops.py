@@ -50,6 +50,7 @@ class ConvSource(NamedTuple):
     tensor: torch.Tensor                    # [N,C,H,W], or [N,C,H/2,W/2] when pixel_shuffle
     scale: Optional[torch.Tensor] = None    # [N,C] multiplier (folded Dropout2d) or None
     pixel_shuffle: bool = False
+    nbatch: int = 0                         # > 0: tensor holds nbatch images, output image n reads image n % nbatch
 
 
 def conv_ck(ksize: int) -> int:
@@ -131,6 +132,10 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
             sh, sw, contributed = sh * 2, sw * 2, sc // 4
         else:
             contributed = sc
+        if s.nbatch:
+            if i == 0 or sn != s.nbatch or n % sn:
+                raise RuntimeError(f"src[{i}]: a batch-broadcast source must follow a full-batch source and divide N")
+            sn = n
         if n is None:
             n, h, w = sn, sh, sw
         elif (sn, sh, sw) != (n, h, w):
@@ -139,6 +144,7 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
             _req(s.scale, f"src[{i}].scale")
             if tuple(s.scale.shape) != (sn, sc):
                 raise RuntimeError(f"src[{i}].scale: expected {(sn, sc)}, got {tuple(s.scale.shape)}")
+        d.src[i].nbatch = int(s.nbatch)
         d.src[i].ptr = t.data_ptr()
         d.src[i].scale = _ptr(s.scale)
         d.src[i].C = sc
@@ -194,6 +200,22 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
     TIMING.append((buf.value.decode(), flops, nbytes, e0, e1))
     TIMING_TAGS.append(f"N{n} {cin}->{cout} k{ksize}d{dil} {h}x{w}")
     return out
+
+
+def avgpool3s2_bcast(x: torch.Tensor, scale: Optional[torch.Tensor], n_out: int) -> torch.Tensor:
+    """avgpool3s2 of x[n % B] * scale[n] for n < n_out: pools a B-image tensor into n_out = T*B stacked passes."""
+    _req(x, "x")
+    b, c, h, w = x.shape
+    if n_out % b:
+        raise RuntimeError("avgpool3s2_bcast: n_out must be a multiple of the input batch")
+    if scale is not None:
+        _req(scale, "scale")
+        if tuple(scale.shape) != (n_out, c):
+            raise RuntimeError(f"scale: expected {(n_out, c)}, got {tuple(scale.shape)}")
+    y = torch.empty((n_out, c, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_avgpool3s2_bcast_fwd(x.data_ptr(), _ptr(scale), y.data_ptr(), n_out, b, c, h, w, _stream()),
+          "slu_avgpool3s2_bcast_fwd")
+    return y
 
 
 def avgpool3s2(x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:

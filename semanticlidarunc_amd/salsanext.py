@@ -154,14 +154,18 @@ class ResBlock(_FusedBlock):
         self.bn4 = nn.BatchNorm2d(out_filters)
         self.dropout = nn.Dropout2d(p=dropout_rate)
 
-    def forward(self, x, _scales=None, _name=""):
-        """pooling: (pooled, full_res);  else: (full_res, deferred dropout multiplier or None)."""
+    def features(self, x):
+        """The block up to (not including) dropout / pooling: deterministic given x."""
         src = [ConvSource(x)]
         shortcut = self._run(self.conv1, None, src)
         a1 = self._run(self.conv2, self.bn1, src)
         a2 = self._run(self.conv3, self.bn2, [ConvSource(a1)])
         a3 = self._run(self.conv4, self.bn3, [ConvSource(a2)])
-        full = self._run(self.conv5, self.bn4, [ConvSource(a1), ConvSource(a2), ConvSource(a3)], resid=shortcut)
+        return self._run(self.conv5, self.bn4, [ConvSource(a1), ConvSource(a2), ConvSource(a3)], resid=shortcut)
+
+    def forward(self, x, _scales=None, _name=""):
+        """pooling: (pooled, full_res);  else: (full_res, deferred dropout multiplier or None)."""
+        full = self.features(x)
         s = None
         if self.drop_out:
             s = _draw(self.dropout, full.shape[0], full.shape[1], full.device, _scales, _name + ".dropout")
@@ -187,8 +191,9 @@ class UpBlock(_FusedBlock):
         self.bn4 = nn.BatchNorm2d(out_filters)
         self.dropout3 = nn.Dropout2d(p=dropout_rate)
 
-    def forward(self, x, skip, x_scale=None, _scales=None, _name=""):
+    def forward(self, x, skip, x_scale=None, _scales=None, _name="", skip_nbatch=0):
         """x is read through PixelShuffle(2); x_scale is the producer's deferred dropout multiplier.
+        skip_nbatch > 0: `skip` holds that many images shared by the stacked MC passes.
         Returns (out, deferred multiplier of dropout3 or None)."""
         n, cx, dev = x.shape[0], x.shape[1], x.device
         cu, cs = cx // 4, skip.shape[1]
@@ -204,7 +209,7 @@ class UpBlock(_FusedBlock):
                 sx = _mul(sx, up.repeat_interleave(4, dim=1))
         if sx is not None:
             sx = sx.contiguous()
-        e1 = self._run(self.conv1, self.bn1, [ConvSource(x, sx, True), ConvSource(skip, ss)])
+        e1 = self._run(self.conv1, self.bn1, [ConvSource(x, sx, True), ConvSource(skip, ss, False, skip_nbatch)])
         e2 = self._run(self.conv2, self.bn2, [ConvSource(e1)])
         e3 = self._run(self.conv3, self.bn3, [ConvSource(e2)])
         out = self._run(self.conv4, self.bn4, [ConvSource(e1), ConvSource(e2), ConvSource(e3)])
@@ -241,6 +246,37 @@ class SalsaNext(_FusedBlock):
         """Same as forward() but with the Dropout2d multipliers given explicitly
         (site name -> [B,C,1,1] or [B,C]; missing site = identity).  Used by the parity tests."""
         return self._forward(x, scales)
+
+    @torch.no_grad()
+    def forward_mc(self, x, T: int, scales: Optional[Dict[str, torch.Tensor]] = None):
+        """T stochastic passes of a batch x[B,...] -> logits [T*B, ncls, H, W] (pass-major), computing the part of
+        the network that no active Dropout2d can reach ONCE: the three context blocks, resBlock1 and the convs of
+        resBlock2 see the same input in every pass (resBlock1 is built with drop_out=False and resBlock2's dropout
+        sits after its convs, reference SalsaNext.py:98-101,183-184), so their outputs -- and the two skip tensors
+        they feed to upBlock3 / upBlock4 -- are identical in all T passes.  Results equal T full forwards with the
+        same multipliers; 48 % of the conv FLOPs are not repeated T times.  Inference only (BatchNorm must be frozen)."""
+        if self.training or any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)):
+            raise RuntimeError("forward_mc needs eval-mode BatchNorm (use utils.mc_dropout.mc_forward)")
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or not x.is_cuda:
+            raise RuntimeError("forward_mc expects a [B, C, H, W] tensor on the GPU")
+        if x.shape[2] % 16 or x.shape[3] % 16:
+            raise RuntimeError("SalsaNext needs H and W divisible by 16")
+        b = x.shape[0]
+        n = int(T) * b
+        x = x.contiguous().float()
+        d = self.downCntx3(self.downCntx2(self.downCntx(x)))
+        d0c, d0b = self.resBlock1(d, scales, "resBlock1")               # no dropout in this block
+        full2 = self.resBlock2.features(d0c)                             # deterministic; also the skip of upBlock3
+        s2 = _draw(self.resBlock2.dropout, n, full2.shape[1], x.device, scales, "resBlock2.dropout")
+        d1c = ops.avgpool3s2_bcast(full2, s2, n)                         # from here on: T*B stacked passes
+        d2c, d2b = self.resBlock3(d1c, scales, "resBlock3")
+        d3c, d3b = self.resBlock4(d2c, scales, "resBlock4")
+        d5c, s5 = self.resBlock5(d3c, scales, "resBlock5")
+        u4, s = self.upBlock1(d5c, d3b, s5, scales, "upBlock1")
+        u3, s = self.upBlock2(u4, d2b, s, scales, "upBlock2")
+        u2, s = self.upBlock3(u3, full2, s, scales, "upBlock3", skip_nbatch=b)
+        u1, _ = self.upBlock4(u2, d0b, s, scales, "upBlock4", skip_nbatch=b)
+        return self._run(self.logits, None, [ConvSource(u1)], act=False)
 
     def _forward(self, x, scales):
         if not isinstance(x, torch.Tensor) or x.dim() != 4:

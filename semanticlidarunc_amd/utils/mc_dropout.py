@@ -39,13 +39,19 @@ def dropout_sampling(module: nn.Module, enable: bool = True):
             set_dropout_mode(module, False)
 
 
-def _stacked_passes(model, inputs, T: int):
+def _stacked_passes(model, inputs, T: int, share_prefix: bool = False):
     """Yield logits [t,B,C,H,W] for groups of passes that together cover T passes."""
     inputs = list(inputs)
     b = inputs[0].shape[0]
     done = 0
+    shared = share_prefix and len(inputs) == 1 and hasattr(model, "forward_mc")
     while done < T:
         t = min(MAX_STACK, T - done)
+        if shared:
+            out = model.forward_mc(inputs[0], t)
+            yield out.reshape(t, b, *out.shape[1:])
+            done += t
+            continue
         stacked = [x.repeat(t, *([1] * (x.dim() - 1))) for x in inputs]
         out = model(*stacked)
         if isinstance(out, tuple):
@@ -57,11 +63,13 @@ def _stacked_passes(model, inputs, T: int):
 
 
 @torch.no_grad()
-def mc_forward(model: nn.Module, inputs, T: int = 30):
-    """[T,B,C,H,W] raw model outputs of T stochastic passes (reference mc_dropout.py:98-119)."""
+def mc_forward(model: nn.Module, inputs, T: int = 30, share_prefix: bool = False):
+    """[T,B,C,H,W] raw model outputs of T stochastic passes (reference mc_dropout.py:98-119).
+    share_prefix=True lets a model that implements `forward_mc` compute the layers no active dropout can reach
+    once instead of T times (identical results; see SalsaNext.forward_mc)."""
     model.eval()
     with dropout_sampling(model, enable=True):
-        parts = list(_stacked_passes(model, inputs, T))
+        parts = list(_stacked_passes(model, inputs, T, share_prefix))
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
 
@@ -93,7 +101,7 @@ def predictive_entropy_mc(mc_probs: torch.Tensor, eps: float = 1e-12, normalize:
 
 
 @torch.no_grad()
-def mc_predict(model: nn.Module, inputs, T: int = 30, eps: float = 1e-12):
+def mc_predict(model: nn.Module, inputs, T: int = 30, eps: float = 1e-12, share_prefix: bool = False):
     """The whole MC evaluation step of trainer.py:1138-1154 in one call:
     (p_bar[B,C,H,W], H_norm[B,H,W], MI_norm[B,H,W], preds[B,H,W])."""
-    return ops.mc_reduce(mc_forward(model, inputs, T).contiguous(), eps)
+    return ops.mc_reduce(mc_forward(model, inputs, T, share_prefix).contiguous(), eps)

@@ -98,3 +98,38 @@ def test_weight_update_invalidates_packed_cache(cuda):
     with torch.no_grad():
         m(x)
     assert not torch.equal(before, m.downCntx.bn1.running_mean)
+
+
+def test_shared_prefix_mc_forward_equals_full_passes(cuda, model):
+    """forward_mc (deterministic prefix computed once) == T stacked full forwards with the same multipliers,
+    in both conv precisions; and through mc_forward / mc_predict."""
+    from oracle import salsanext as osalsa_
+    from semanticlidarunc_amd import salsanext as sn
+    from semanticlidarunc_amd.utils.mc_dropout import mc_predict
+    x, _ = synthetic_scan(2, 32, 128, seed=17)
+    x = x.to(cuda)
+    T = 3
+    scales = osalsa_.draw_dropout_scales(T * 2, 0.2, torch.Generator().manual_seed(11))
+    for prec in ("fp32", "f16x3"):
+        sn.set_conv_precision(prec)
+        try:
+            with torch.no_grad():
+                full = model.forward_with_dropout_scales(x.repeat(T, 1, 1, 1), scales)
+                shared = model.forward_mc(x, T, scales)
+        finally:
+            sn.set_conv_precision("fp32")
+        assert shared.shape == full.shape
+        assert float((shared - full).abs().max()) <= 1e-6, prec
+    torch.manual_seed(5)
+    a = mc_forward(model, [x], T=4, share_prefix=True)
+    torch.manual_seed(5)
+    b = mc_forward(model, [x], T=4, share_prefix=False)
+    assert a.shape == b.shape == (4, 2, 20, 32, 128)
+    # same seed -> the same Dropout2d draws in the same order -> the two schedules agree to the last bit
+    assert float((a - b).abs().max()) <= 1e-6 and float(a.std(0).mean()) > 1e-3
+    p_bar, h, mi, preds = mc_predict(model, [x], T=4, share_prefix=True)
+    assert p_bar.shape == (2, 20, 32, 128) and float((p_bar.sum(1) - 1).abs().max()) < 1e-5
+    model.train()
+    with pytest.raises(RuntimeError):
+        model.forward_mc(x, 2)
+    model.eval()
