@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 3
+#define SLU_ABI_VERSION 4
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -49,7 +49,7 @@ const char* slu_strerror(int code);
  * PixelShuffle(2) and multiplied by a per-(n, source-channel) factor (folded Dropout2d).
  * `out` must not overlap any input (sources, resid).  Stride 1, "same" output size; kernel families (ksize,dil,pad) = (1,1,0) (3,1,1) (3,2,2) (2,2,1).
  * ------------------------------------------------------------------------------------------ */
-#define SLU_MAX_SRC 3
+#define SLU_MAX_SRC 4
 
 typedef struct slu_conv_src {
   const float* ptr;    /* [N, C, H, W]  or, when pixel_shuffle, [N, C, H/2, W/2]                */
@@ -58,7 +58,8 @@ typedef struct slu_conv_src {
   int32_t pixel_shuffle; /* 1: contributes C/4 channels, in[c,y,x] = ptr[4c+2(y&1)+(x&1), y/2, x/2] */
   int32_t nbatch;      /* 0: the tensor holds N images; k > 0: it holds k images and output image n reads image n % k
                           (a deterministic skip tensor shared by the stacked MC passes); `scale` stays [N, C]      */
-  int32_t reserved_;
+  int32_t cuse;        /* 0: every channel contributes; k > 0: only the first k channels do (the reference overwrites the
+                          last meta_channel_dim channels of a stage output: x[:, :-m], semanticFCN.py:309-313)      */
 } slu_conv_src;
 
 typedef struct slu_conv_desc {   /* HOST struct */
@@ -70,7 +71,8 @@ typedef struct slu_conv_desc {   /* HOST struct */
   int32_t ck;            /* K-chunk the weights were packed with (slu_conv_ck)                   */
   const float* wpack;    /* slu_pack_conv_weight output                                          */
   const float* bias;     /* [Cout] or NULL                                                       */
-  int32_t has_act;       /* 1: leaky(v) = v > 0 ? v : slope * v                                  */
+  int32_t has_act;       /* 0 none; 1: leaky(v) = v > 0 ? v : slope * v (slope 0 = ReLU); 2: tanh(v);
+                            +4: apply it after bn_a/bn_b and the residual add (ResNet BasicBlock) instead of before */
   float slope;
   const float* bn_a;     /* [Cout] or NULL (then bn_b ignored): folded eval BatchNorm            */
   const float* bn_b;
@@ -213,6 +215,22 @@ int slu_dgrad_weight(const float* w, int cout, int cin, int ksize, float* wd, sl
 size_t slu_wgrad_packed_floats(int cout, int cin, int ksize);
 int slu_conv2d_wgrad(const float* da_t, const float* in_t, int N, int H, int W, int Cout, int Cin, int ksize, int dil, int pad,
                      float* dWp, float* dW, slu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ResNet-FPN pieces (models/semanticFCN.py:145-153, 230-245, 266-354): data movement around the conv kernel.
+ * ------------------------------------------------------------------------------------------ */
+/* nn.MaxPool2d(3, 2, 1): x [N,C,H,W] -> y [N,C,(H+1)/2,(W+1)/2] */
+int slu_maxpool3s2_fwd(const float* x, float* y, int N, int C, int H, int W, slu_stream_t stream);
+/* F.interpolate(mode='nearest', scale_factor=1/factor): y[..,oy,ox] = x[..,oy*factor,ox*factor] */
+int slu_nearest_down(const float* x, float* y, int N, int C, int H, int W, int factor, slu_stream_t stream);
+/* y[n,(2p+q)*C+c,oy,ox] = x[n,c,2oy+p,2ox+q]: a stride-2 3x3/p1 conv on x == a (2,1,1) conv on y with re-indexed weights */
+int slu_space_to_depth2(const float* x, float* y, int N, int C, int H, int W, slu_stream_t stream);
+/* the same of cat(a[:, :ca], b) (a [N,Ca,H,W], b [N,Cb,H,W]) -> y [N, 4*(ca+Cb), H/2, W/2] */
+int slu_space_to_depth2_cat(const float* a, int Ca, int ca, const float* b, int Cb, float* y, int N, int H, int W, slu_stream_t stream);
+/* nn.PixelShuffle(r) of x [N,Cout*r*r,H,W] -> y [N,Cout,H*r,W*r], optionally followed by ELU(v)+1 */
+int slu_depth_to_space(const float* x, float* y, int N, int Cout, int H, int W, int r, int elu_plus_one, slu_stream_t stream);
+/* out = value * softmax(score, dim=-1): score [N,1,H,W], value/out [N,C,H,W]; W <= 4096 (AttentionModule :32-38) */
+int slu_row_softmax_mul(const float* score, const float* value, float* out, int N, int C, int H, int W, slu_stream_t stream);
 
 #ifdef __cplusplus
 }

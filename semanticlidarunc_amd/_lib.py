@@ -9,8 +9,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 3
-MAX_SRC = 3
+ABI_VERSION = 4
+MAX_SRC = 4
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
 
@@ -22,7 +22,7 @@ c_stream = C.c_void_p
 
 class ConvSrc(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("C", C.c_int32), ("pixel_shuffle", C.c_int32),
-                ("nbatch", C.c_int32), ("reserved_", C.c_int32)]
+                ("nbatch", C.c_int32), ("cuse", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -84,6 +84,12 @@ SIGNATURES = {
     "slu_wgrad_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_conv2d_wgrad": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    c_f32p, c_f32p, c_stream]),
+    "slu_maxpool3s2_fwd": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_nearest_down": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_space_to_depth2": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_space_to_depth2_cat": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_depth_to_space": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_row_softmax_mul": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_lovasz_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_lovasz_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_size_t, c_f32p,
                                  c_f32p, c_f32p, c_stream]),

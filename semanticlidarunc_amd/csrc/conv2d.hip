@@ -174,9 +174,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         const bool ok = pix_ok && co < a.Cout;
         const size_t o = ok ? ((size_t)n * a.Cout + co) * plane + (size_t)gy * a.W + gx : 0;
         float v = acc[i][b][r] + s_epi[cl];
-        if (a.has_act) v = v > 0.0f ? v : v * a.slope;
+        const int act = a.has_act & 3, late = a.has_act & 4;          // late: activation after BatchNorm + residual
+        if (!late) {
+          if (act == 1) v = v > 0.0f ? v : v * a.slope;
+          else if (act == 2) v = tanhf(v);
+        }
         v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
         if (resid) v += resid[o];
+        if (late) {
+          if (act == 1) v = v > 0.0f ? v : v * a.slope;
+          else if (act == 2) v = tanhf(v);
+        }
         if (ok) out[o] = v;
       }
     }
@@ -268,6 +276,7 @@ extern "C" int slu_conv2d_fwd(const slu_conv_desc* d, slu_stream_t stream) {
   if (d->ksize == 3 && d->dil == 1 && d->pad == 1) return launch_family<3, 1, 1, 8>(a, cfg, st);
   if (d->ksize == 3 && d->dil == 2 && d->pad == 2) return launch_family<3, 2, 2, 8>(a, cfg, st);
   if (d->ksize == 2 && d->dil == 2 && d->pad == 1) return launch_family<2, 2, 1, 8>(a, cfg, st);
+  if (d->ksize == 2 && d->dil == 1 && d->pad == 1) return launch_family<2, 1, 1, 8>(a, cfg, st);
   return SLU_EUNSUPPORTED;
 }
 

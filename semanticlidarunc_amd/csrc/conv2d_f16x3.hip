@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
         // inside the image: one base address, constant channel stride, no per-channel selects
         const int cg0 = q * CK16 + g2 * 8;
         const SrcPick p0 = pick_src(a, (pix_ok && cg0 < a.Cin) ? cg0 : 0);
-        fast = pix_ok && cg0 + 8 <= a.Cin && p0.cl + 8 <= p0.C;
+        fast = pix_ok && cg0 + 8 <= a.Cin && p0.cl + 8 <= p0.cc;
         if (fast) {
           const size_t cs = (size_t)a.H * a.W;
           const int ns = p0.nb ? n % p0.nb : n;
@@ -271,9 +271,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
         const bool ok = pix_ok && co < a.Cout;
         const size_t o = ok ? ((size_t)n * a.Cout + co) * plane + (size_t)gy * a.W + gx : 0;
         float v = acc[i][b][r] + s_epi[cl];
-        if (a.has_act) v = v > 0.0f ? v : v * a.slope;
+        const int act = a.has_act & 3, late = a.has_act & 4;          // late: activation after BatchNorm + residual
+        if (!late) {
+          if (act == 1) v = v > 0.0f ? v : v * a.slope;
+          else if (act == 2) v = tanhf(v);
+        }
         v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
         if (resid) v += resid[o];
+        if (late) {
+          if (act == 1) v = v > 0.0f ? v : v * a.slope;
+          else if (act == 2) v = tanhf(v);
+        }
         if (ok) out[o] = v;
       }
     }
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             // channels past the end of the source (ragged tail / K padding): read element 0 instead, use 0
-            const bool ok = live[b] && c0 < a.Cin && cl0 + k < S.C;
+            const bool ok = live[b] && c0 < a.Cin && cl0 + k < S.ccount;
             const float v = S.ptr[ok ? base + (size_t)k * HW : 0];
             x[ks][b][k] = ok ? v : 0.0f;
           }
@@ -420,9 +428,17 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
         const bool ok = live[b] && co < a.Cout;
         const size_t o = ok ? ((size_t)img[b] * a.Cout + co) * HW + hw[b] : 0;
         float v = acc[i][b][r] + s_epi[co];
-        if (a.has_act) v = v > 0.0f ? v : v * a.slope;
+        const int act = a.has_act & 3, late = a.has_act & 4;          // late: activation after BatchNorm + residual
+        if (!late) {
+          if (act == 1) v = v > 0.0f ? v : v * a.slope;
+          else if (act == 2) v = tanhf(v);
+        }
         v = v * s_epi[MB * 32 + co] + s_epi[2 * MB * 32 + co];
         if (resid) v += resid[o];
+        if (late) {
+          if (act == 1) v = v > 0.0f ? v : v * a.slope;
+          else if (act == 2) v = tanhf(v);
+        }
         if (ok) out[o] = v;
       }
 }
@@ -559,5 +575,6 @@ int slu_conv2d_fwd_f16x3_impl(const slu_conv_desc* d, hipStream_t st) {
   if (d->ksize == 3 && d->dil == 1 && d->pad == 1) return launch_family16<3, 1, 1>(a, cfg, st);
   if (d->ksize == 3 && d->dil == 2 && d->pad == 2) return launch_family16<3, 2, 2>(a, cfg, st);
   if (d->ksize == 2 && d->dil == 2 && d->pad == 1) return launch_family16<2, 2, 1>(a, cfg, st);
+  if (d->ksize == 2 && d->dil == 1 && d->pad == 1) return launch_family16<2, 1, 1>(a, cfg, st);
   return SLU_EUNSUPPORTED;
 }

@@ -40,13 +40,13 @@ struct ConvArgs {
 struct SrcPick {
   const float* ptr;
   const float* scale;
-  int C, cl, ps, nb;
+  int C, cl, ps, nb, cc;   // cc = channels this source contributes (<= C when only a prefix is used)
 };
 __device__ __forceinline__ SrcPick pick_src(const ConvArgs& a, int cg) {
-  SrcPick p{a.src[0].ptr, a.src[0].scale, a.src[0].C, cg, a.src[0].ps, a.src[0].nb};
+  SrcPick p{a.src[0].ptr, a.src[0].scale, a.src[0].C, cg, a.src[0].ps, a.src[0].nb, a.src[0].ccount};
 #pragma unroll
   for (int s = 1; s < SLU_MAX_SRC; ++s)
-    if (s < a.nsrc && cg >= a.src[s].cbeg) p = SrcPick{a.src[s].ptr, a.src[s].scale, a.src[s].C, cg - a.src[s].cbeg, a.src[s].ps, a.src[s].nb};
+    if (s < a.nsrc && cg >= a.src[s].cbeg) p = SrcPick{a.src[s].ptr, a.src[s].scale, a.src[s].C, cg - a.src[s].cbeg, a.src[s].ps, a.src[s].nb, a.src[s].ccount};
   return p;
 }
 
@@ -162,7 +162,8 @@ inline int fill_args(const slu_conv_desc* d, ConvArgs& a) {
     a.src[s].C = S.C;
     a.src[s].ps = S.pixel_shuffle ? 1 : 0;
     a.src[s].cbeg = c;
-    a.src[s].ccount = S.pixel_shuffle ? S.C / 4 : S.C;
+    a.src[s].ccount = S.pixel_shuffle ? S.C / 4 : (S.cuse > 0 ? S.cuse : S.C);
+    if (S.cuse < 0 || S.cuse > S.C || (S.cuse && S.pixel_shuffle)) return SLU_EINVAL;
     a.src[s].nb = S.nbatch > 0 ? S.nbatch : 0;
     c += a.src[s].ccount;
   }

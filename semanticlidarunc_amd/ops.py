@@ -51,6 +51,7 @@ class ConvSource(NamedTuple):
     scale: Optional[torch.Tensor] = None    # [N,C] multiplier (folded Dropout2d) or None
     pixel_shuffle: bool = False
     nbatch: int = 0                         # > 0: tensor holds nbatch images, output image n reads image n % nbatch
+    cuse: int = 0                           # > 0: only the first cuse channels of the tensor contribute
 
 
 def conv_ck(ksize: int) -> int:
@@ -109,7 +110,7 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
                  bias: Optional[torch.Tensor] = None, slope: Optional[float] = None,
                  bn_a: Optional[torch.Tensor] = None, bn_b: Optional[torch.Tensor] = None,
                  resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                 precision: str = "fp32") -> torch.Tensor:
+                 precision: str = "fp32", act: Optional[str] = None, act_after_resid: bool = False) -> torch.Tensor:
     """out = resid + bn_a * leaky(conv(cat(srcs)) + bias) + bn_b   (see slu_conv2d_fwd).
     precision 'fp32' (exact, wpack from pack_conv_weight) or 'f16x3' (split-fp16, wpack from pack_conv_weight_f16x3)."""
     if precision not in PRECISIONS:
@@ -130,6 +131,10 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
             if sc % 4:
                 raise RuntimeError(f"src[{i}]: PixelShuffle(2) needs C % 4 == 0")
             sh, sw, contributed = sh * 2, sw * 2, sc // 4
+        elif s.cuse:
+            if not 0 < s.cuse <= sc:
+                raise RuntimeError(f"src[{i}]: cuse must be in 1..C")
+            contributed = s.cuse
         else:
             contributed = sc
         if s.nbatch:
@@ -145,6 +150,7 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
             if tuple(s.scale.shape) != (sn, sc):
                 raise RuntimeError(f"src[{i}].scale: expected {(sn, sc)}, got {tuple(s.scale.shape)}")
         d.src[i].nbatch = int(s.nbatch)
+        d.src[i].cuse = int(s.cuse)
         d.src[i].ptr = t.data_ptr()
         d.src[i].scale = _ptr(s.scale)
         d.src[i].C = sc
@@ -183,6 +189,12 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
     d.ksize, d.dil, d.pad, d.ck = ksize, dil, pad, ck
     d.wpack, d.bias = wpack.data_ptr(), _ptr(bias)
     d.has_act, d.slope = (0, 0.0) if slope is None else (1, float(slope))
+    if act is not None:                     # explicit activation kind overrides `slope`
+        if act not in ("relu", "tanh", "none"):
+            raise ValueError(f"unknown activation {act!r}")
+        d.has_act, d.slope = {"relu": (1, 0.0), "tanh": (2, 0.0), "none": (0, 0.0)}[act]
+    if act_after_resid and d.has_act:
+        d.has_act |= 4
     d.bn_a, d.bn_b, d.resid, d.out = _ptr(bn_a), _ptr(bn_b), _ptr(resid), out.data_ptr()
     d.precision = PRECISIONS[precision]
     if TIMING is None:
@@ -532,3 +544,73 @@ def conv2d_wgrad(da_t, in_t, n, h, w, cout, cin, ksize, dil, pad):
     check(lib.slu_conv2d_wgrad(da_t.data_ptr(), in_t.data_ptr(), n, h, w, cout, cin, ksize, dil, pad, scratch.data_ptr(), dw.data_ptr(),
                                _stream()), "slu_conv2d_wgrad")
     return dw
+
+
+# ------------------------------------------------------------------------------------------------
+# ResNet-FPN data movement
+# ------------------------------------------------------------------------------------------------
+def maxpool3s2(x):
+    _req(x, "x")
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_maxpool3s2_fwd(x.data_ptr(), y.data_ptr(), n, c, h, w, _stream()), "slu_maxpool3s2_fwd")
+    return y
+
+
+def nearest_down(x, factor: int):
+    _req(x, "x")
+    n, c, h, w = x.shape
+    if h % factor or w % factor:
+        raise RuntimeError("nearest_down: H and W must be multiples of the factor")
+    y = torch.empty((n, c, h // factor, w // factor), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_nearest_down(x.data_ptr(), y.data_ptr(), n, c, h, w, int(factor), _stream()), "slu_nearest_down")
+    return y
+
+
+def space_to_depth2(x):
+    """[N,C,H,W] -> [N,4C,H/2,W/2], channel (2p+q)*C + c = x[c, 2y+p, 2x+q]."""
+    _req(x, "x")
+    n, c, h, w = x.shape
+    if h % 2 or w % 2:
+        raise RuntimeError("space_to_depth2: H and W must be even")
+    y = torch.empty((n, 4 * c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_space_to_depth2(x.data_ptr(), y.data_ptr(), n, c, h, w, _stream()), "slu_space_to_depth2")
+    return y
+
+
+def space_to_depth2_cat(a, ca: int, b):
+    """space_to_depth2 of cat(a[:, :ca], b) without materialising the concatenation."""
+    _req(a, "a")
+    _req(b, "b")
+    n, ca_full, h, w = a.shape
+    if b.shape[0] != n or tuple(b.shape[2:]) != (h, w) or not 0 < ca <= ca_full or h % 2 or w % 2:
+        raise RuntimeError("space_to_depth2_cat: shape mismatch")
+    cb = b.shape[1]
+    y = torch.empty((n, 4 * (ca + cb), h // 2, w // 2), dtype=torch.float32, device=a.device)
+    check(_lib.load().slu_space_to_depth2_cat(a.data_ptr(), ca_full, int(ca), b.data_ptr(), cb, y.data_ptr(), n, h, w, _stream()),
+          "slu_space_to_depth2_cat")
+    return y
+
+
+def depth_to_space(x, r: int, elu_plus_one: bool = False):
+    """nn.PixelShuffle(r), optionally followed by ELU(v) + 1."""
+    _req(x, "x")
+    n, c, h, w = x.shape
+    if c % (r * r):
+        raise RuntimeError("depth_to_space: C must be a multiple of r*r")
+    y = torch.empty((n, c // (r * r), h * r, w * r), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_depth_to_space(x.data_ptr(), y.data_ptr(), n, c // (r * r), h, w, int(r), 1 if elu_plus_one else 0, _stream()),
+          "slu_depth_to_space")
+    return y
+
+
+def row_softmax_mul(score, value):
+    """value * softmax(score, dim=-1); score [N,1,H,W], value [N,C,H,W]."""
+    _req(score, "score")
+    _req(value, "value")
+    n, c, h, w = value.shape
+    if tuple(score.shape) != (n, 1, h, w):
+        raise RuntimeError("row_softmax_mul: score must be [N,1,H,W]")
+    out = torch.empty_like(value)
+    check(_lib.load().slu_row_softmax_mul(score.data_ptr(), value.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "slu_row_softmax_mul")
+    return out

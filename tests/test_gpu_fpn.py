@@ -1,0 +1,135 @@
+"""GPU: the ResNet-FPN model and its data-movement kernels against the oracle and the golden
+outputs produced by the reference's own models.semanticFCN wiring.  Bar: 1e-3 abs on the (ELU + 1) outputs."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, golden
+from oracle import fpn as ofpn
+from semanticlidarunc_amd import ops, salsanext as sn
+from semanticlidarunc_amd.fpn import SemanticNetworkWithFPN
+from semanticlidarunc_amd.ops import ConvSource
+from semanticlidarunc_amd.testing import randomize_bn_
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_data_movement_kernels(cuda):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 5, 12, 40, generator=g)
+    assert torch.equal(ops.maxpool3s2(x.to(cuda)).cpu(), F.max_pool2d(x, 3, 2, 1))
+    x16 = torch.randn(2, 3, 16, 48, generator=g)
+    for f in (2, 4, 8):
+        assert torch.equal(ops.nearest_down(x16.to(cuda), f).cpu(), F.interpolate(x16, scale_factor=1 / f, mode="nearest"))
+    s2d = ops.space_to_depth2(x.to(cuda)).cpu()
+    for p in (0, 1):
+        for q in (0, 1):
+            assert torch.equal(s2d[:, (2 * p + q) * 5:(2 * p + q + 1) * 5], x[:, :, p::2, q::2])
+    b = torch.randn(2, 2, 12, 40, generator=g)
+    cat = torch.cat([x[:, :3], b], 1)
+    assert torch.equal(ops.space_to_depth2_cat(x.to(cuda), 3, b.to(cuda)).cpu(), ops.space_to_depth2(cat.to(cuda)).cpu())
+    y = torch.randn(2, 3 * 16, 5, 7, generator=g)
+    assert torch.equal(ops.depth_to_space(y.to(cuda), 4).cpu(), F.pixel_shuffle(y, 4))
+    got = ops.depth_to_space(y.to(cuda), 2, elu_plus_one=True).cpu()
+    assert float((got - (F.elu(F.pixel_shuffle(y, 2)) + 1)).abs().max()) <= 1e-6
+    sc, v = torch.randn(2, 1, 6, 300, generator=g) * 3, torch.randn(2, 7, 6, 300, generator=g)
+    assert float((ops.row_softmax_mul(sc.to(cuda), v.to(cuda)).cpu() - v * torch.softmax(sc, -1)).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_strided_and_transposed_convs_as_fused_launches(cuda, prec):
+    """stride-2 3x3 conv, 1x1/s2 downsample, ConvTranspose k=s and k4/s2/p1, late ReLU, tanh epilogue."""
+    g = torch.Generator().manual_seed(2)
+    sn.set_conv_precision(prec)
+    try:
+        m = SemanticNetworkWithFPN("resnet18", 2, 3, num_classes=5).to(cuda).eval()
+        x = torch.randn(2, 64, 16, 64, generator=g)
+        blk = m.layer2[0]
+        meta = torch.randn(2, 3, 16, 64, generator=g)
+        xin = torch.cat([x[:, :61], meta], 1)
+        s2d = ops.space_to_depth2_cat(x.to(cuda), 61, meta.to(cuda))
+        got = m._conv_s2("t.conv1", blk.conv1, blk.bn1, s2d, 64).cpu()
+        want = F.relu(blk.bn1.cpu()(F.conv2d(xin, blk.conv1.weight.cpu(), None, stride=2, padding=1)))
+        assert float((got - want).abs().max()) <= 1e-4
+        blk.bn1.to(cuda)
+        idn = m._conv("t.down", blk.downsample[0], blk.downsample[1], [ConvSource(s2d, None, False, 0, 64)], act="none").cpu()
+        want = blk.downsample[1].cpu()(F.conv2d(xin, blk.downsample[0].weight.cpu(), None, stride=2))
+        assert float((idn - want).abs().max()) <= 1e-4
+        blk.downsample[1].to(cuda)
+        f = torch.randn(2, 128, 4, 16, generator=g)
+        for name, ct in (("up3", m.upsample_layer_x3), ("up4", m.upsample_layer_x4), ("up2", m.upsample_layer_x2)):
+            fin = torch.randn(2, ct.in_channels, 4, 16, generator=g)
+            got = m._convT_eq_stride("t." + name, ct, fin.to(cuda)).cpu()
+            want = F.conv_transpose2d(fin, ct.weight.cpu(), ct.bias.cpu(), stride=ct.stride)
+            assert float((got - want).abs().max()) <= 1e-4, name
+        ct = m.decoder_semantic[6]
+        fin = torch.randn(2, 32, 8, 32, generator=g)
+        got = m._convT_k4s2p1("t.out", ct, fin.to(cuda), elu_plus_one=True).cpu()
+        want = F.elu(F.conv_transpose2d(fin, ct.weight.cpu(), ct.bias.cpu(), stride=2, padding=1)) + 1
+        assert float((got - want).abs().max()) <= 1e-4
+        # late activation: relu(conv + resid)
+        w = torch.randn(32, 32, 3, 3, generator=g) / 17
+        r = torch.randn(2, 32, 8, 32, generator=g)
+        pack = ops.pack_conv_weight_f16x3(w.to(cuda)) if prec == "f16x3" else ops.pack_conv_weight(w.to(cuda))
+        got = ops.conv2d_fused([ConvSource(fin.to(cuda))], pack, 32, 3, 1, 1, resid=r.to(cuda), precision=prec, act="relu",
+                               act_after_resid=True).cpu()
+        assert float((got - F.relu(F.conv2d(fin, w, None, padding=1) + r)).abs().max()) <= 1e-4
+        got = ops.conv2d_fused([ConvSource(fin.to(cuda))], pack, 32, 3, 1, 1, precision=prec, act="tanh").cpu()
+        assert float((got - torch.tanh(F.conv2d(fin, w, None, padding=1))).abs().max()) <= 1e-4
+    finally:
+        sn.set_conv_precision("fp32")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+@pytest.mark.parametrize("tag,kw", [
+    ("resnet18_m6_c20", dict(backbone="resnet18", input_channels=2, meta_channel_dim=6, num_classes=20)),
+    ("resnet34_m3_c3_noatt", dict(backbone="resnet34", input_channels=2, meta_channel_dim=3, num_classes=3, attention=False,
+                                  multi_scale_meta=False))])
+def test_fpn_matches_reference_golden(cuda, prec, tag, kw):
+    g = golden("fpn_" + tag)
+    torch.manual_seed(0)
+    model = randomize_bn_(SemanticNetworkWithFPN(**kw), 3).eval()
+    sd = model.state_dict()
+    s = sum(float(v.double().sum()) for v in sd.values() if v.is_floating_point())
+    a = sum(float(v.double().abs().sum()) for v in sd.values() if v.is_floating_point())
+    assert np.allclose([s, a], g["sd_digest"], rtol=1e-10)
+    model.to(cuda)
+    sn.set_conv_precision(prec)
+    try:
+        with torch.no_grad():
+            y = model(_t(g["x"]).to(cuda), _t(g["meta"]).to(cuda)).cpu()
+    finally:
+        sn.set_conv_precision("fp32")
+    assert y.shape == g["out"].shape and float(y.min()) >= 0
+    assert float((y - _t(g["out"])).abs().max()) <= 1e-3
+
+
+def test_ouster_shape_against_oracle_and_contract(cuda):
+    # inference_ouster.py: resnet_type= keyword (stale alias), 2 + 6 channels, 128 x 2048 (here 128 x 512 to keep the oracle quick)
+    torch.manual_seed(0)
+    model = randomize_bn_(SemanticNetworkWithFPN(resnet_type="resnet18", meta_channel_dim=6, num_classes=20), 3).eval()
+    want_keys = json.load(open(os.path.join(GOLDEN, "fpn_resnet18_state_dict_keys.json")))
+    assert list(model.state_dict().keys()) == list(want_keys.keys())
+    assert all(list(v.shape) == want_keys[k] for k, v in model.state_dict().items())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    x, meta = torch.randn(1, 2, 128, 512, generator=g), torch.randn(1, 6, 128, 512, generator=g)
+    with torch.no_grad():
+        want = ofpn.fpn_forward(sd, x, meta)
+        with pytest.raises(RuntimeError):
+            model(x, meta)                                   # CPU tensors: no fallback
+        got = model.to(cuda)(x.to(cuda), meta.to(cuda)).cpu()
+    assert float((got - want).abs().max()) <= 1e-3
+    assert float((got.argmax(1) != want.argmax(1)).float().mean()) < 1e-3
+    with pytest.raises(ValueError):
+        SemanticNetworkWithFPN(backbone="resnet19")
+    with pytest.raises(NotImplementedError):
+        SemanticNetworkWithFPN(backbone="resnet50")

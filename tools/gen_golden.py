@@ -225,6 +225,36 @@ def main():
     print(f"ECE reference={e_ref:.6f} oracle={e_or:.6f}; MCE {m_ref:.6f}/{m_or:.6f}")
     save("ece_2x20x16x64", probs=pe, labels=lab_m, n=n, ece=e_ref, mce=m_ref,
          acc=np.nan_to_num(stats_ref["acc"].to_numpy()), conf=np.nan_to_num(stats_ref["conf"].to_numpy()))
+    # ---------------- ResNet-FPN (models/semanticFCN.py) through a stub torchvision serving oracle.fpn.ResNetRef ----------------
+    from oracle import fpn as ofpn
+    from semanticlidarunc_amd.fpn import SemanticNetworkWithFPN as MyFPN
+    from semanticlidarunc_amd.testing import randomize_bn_
+    tv = types.ModuleType("torchvision")
+    tv.models = ofpn.torchvision_models_stub()
+    sys.modules["torchvision"], sys.modules["torchvision.models"] = tv, tv.models
+    from models.semanticFCN import SemanticNetworkWithFPN as RefFPN        # the reference's own wiring
+    for tag, kw, shape in (("resnet18_m6_c20", dict(backbone="resnet18", input_channels=2, meta_channel_dim=6, num_classes=20), (1, 32, 128)),
+                           ("resnet34_m3_c3_noatt", dict(backbone="resnet34", input_channels=2, meta_channel_dim=3, num_classes=3,
+                                                         attention=False, multi_scale_meta=False), (2, 16, 64))):
+        torch.manual_seed(0)
+        mine = randomize_bn_(MyFPN(**kw), 3).eval()
+        ref_f = RefFPN(**kw)
+        sdf = mine.state_dict()
+        assert list(sdf.keys()) == list(ref_f.state_dict().keys())
+        ref_f.load_state_dict(sdf)
+        ref_f.eval()
+        g = torch.Generator().manual_seed(51)
+        xf = torch.randn(shape[0], 2, shape[1], shape[2], generator=g) * torch.tensor([20.0, 0.3]).view(1, 2, 1, 1)
+        mf = torch.randn(shape[0], kw["meta_channel_dim"], shape[1], shape[2], generator=g) * 5.0
+        with torch.no_grad():
+            yr = ref_f(xf, mf)
+            yo = ofpn.fpn_forward(sdf, xf, mf, kw["backbone"], kw.get("attention", True), kw.get("multi_scale_meta", True))
+        print(f"FPN {tag}: |oracle - reference| = {maxdiff(yr, yo):.3e}  (out min {float(yr.min()):.3f})")
+        assert maxdiff(yr, yo) <= 1e-5
+        save("fpn_" + tag, x=xf, meta=mf, out=yr, sd_digest=sd_digest({k: v for k, v in sdf.items() if v.is_floating_point()}))
+    with open(os.path.join(OUT, "fpn_resnet18_state_dict_keys.json"), "w") as f:
+        torch.manual_seed(0)
+        json.dump({k: list(v.shape) for k, v in RefFPN("resnet18", 2, 6, num_classes=20).state_dict().items()}, f, indent=0)
     print("all oracle functions pinned against the reference")
 
 
