@@ -192,6 +192,16 @@ int slu_bn_stats(const float* y, int N, int C, int HW, double* sum, double* sums
 /* s1[c] += sum dz, s2[c] += sum dz * (y - mean[c]) * invstd[c] */
 int slu_bn_bwd_reduce(const float* dz, const float* y, const float* mean, const float* invstd, int N, int C, int HW,
                       double* s1, double* s2, slu_stream_t stream);
+/* per-channel BatchNorm coefficients in one launch (fp64 inside).  train != 0: statistics from sum/sumsq over `count` elements
+ * (biased variance), running_mean/var updated in place with `momentum` and the unbiased variance (nullable: no update);
+ * train == 0: statistics = running_mean/var.  Outputs mean, invstd, a = gamma*invstd, b = beta - mean*a (all [C]). */
+int slu_bn_coeffs_fwd(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float eps,
+                      float momentum, int train, float* running_mean, float* running_var, int C, float* mean, float* invstd,
+                      float* a, float* b, slu_stream_t stream);
+/* backward coefficients for slu_act_affine_bwd from slu_bn_bwd_reduce sums: k1 = gamma*invstd; train: k3 = -gamma*invstd^2*s2/count,
+ * k2 = -gamma*invstd*s1/count - k3*mean; eval: k2 = k3 = 0; dgamma = s2, dbeta = s1 */
+int slu_bn_coeffs_bwd(const double* s1, const double* s2, double count, const float* gamma, const float* mean, const float* invstd,
+                      int train, int C, float* k1, float* k2, float* k3, float* dgamma, float* dbeta, slu_stream_t stream);
 /* z = a[c]*y + b[c] + resid   (a, b, resid nullable: 1, 0, 0) */
 int slu_affine_fwd(const float* y, const float* a, const float* b, const float* resid, float* z, int N, int C, int HW,
                    slu_stream_t stream);

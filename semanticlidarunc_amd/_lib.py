@@ -72,6 +72,10 @@ SIGNATURES = {
                                        C.c_int, c_f32p, c_stream]),
     "slu_bn_stats": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, c_stream]),
     "slu_bn_bwd_reduce": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, c_stream]),
+    "slu_bn_coeffs_fwd": (C.c_int, [c_f64p, c_f64p, C.c_double, c_f32p, c_f32p, C.c_float, C.c_float, C.c_int, c_f32p, c_f32p, C.c_int,
+                                    c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "slu_bn_coeffs_bwd": (C.c_int, [c_f64p, c_f64p, C.c_double, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
+                                    c_f32p, c_f32p, c_stream]),
     "slu_affine_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_act_affine_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                      c_f32p, c_f64p, c_stream]),

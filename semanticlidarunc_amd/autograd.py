@@ -38,23 +38,18 @@ class ConvLayerFn(torch.autograd.Function):
         if bn is not None:
             n, c, h, w = y.shape
             m = n * h * w
-            if bn.training:
-                train_stats = True
-                s, q = ops.bn_stats(y)
-                mean64 = s / m
-                var64 = (q / m - mean64 * mean64).clamp_min(0.0)
+            train_stats = bool(bn.training)
+            sums = ops.bn_stats(y) if train_stats else None
+            mom = 0.0
+            track = train_stats and bn.track_running_stats and bn.running_mean is not None
+            if track:
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+            mean, invstd, a, b = ops.bn_coeffs_fwd(sums, m, gamma.detach(), beta.detach(), bn.eps, mom,
+                                                   bn.running_mean if (track or not train_stats) else None,
+                                                   bn.running_var if (track or not train_stats) else None, train_stats)
+            if track:
                 with torch.no_grad():
-                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                    if bn.track_running_stats and bn.running_mean is not None:
-                        bn.running_mean.mul_(1.0 - mom).add_(mean64.float(), alpha=mom)
-                        bn.running_var.mul_(1.0 - mom).add_((var64 * (m / max(1, m - 1))).float(), alpha=mom)
-                        bn.num_batches_tracked += 1
-            else:
-                mean64, var64 = bn.running_mean.double(), bn.running_var.double()
-            invstd64 = torch.rsqrt(var64 + bn.eps)
-            a = (gamma.detach().double() * invstd64).float()
-            b = (beta.detach().double() - mean64 * gamma.detach().double() * invstd64).float()
-            mean, invstd = mean64.float(), invstd64.float()
+                    bn.num_batches_tracked += 1
             z = ops.affine(y, a, b, None if resid is None else resid.detach().contiguous())
         elif resid is not None:
             z = ops.affine(y, None, None, resid.detach().contiguous())
@@ -85,14 +80,9 @@ class ConvLayerFn(torch.autograd.Function):
         if ctx.has_bn:
             gamma, mean, invstd = saved[2 + nsrc:5 + nsrc]
             s1, s2 = ops.bn_bwd_reduce(dz, y, mean, invstd)
-            dgamma, dbeta = s2.float(), s1.float()
-            g64, is64 = gamma.detach().double(), invstd.double()
-            k1 = (g64 * is64).float()
-            if ctx.train_stats:
-                m = float(n * h * w)
-                k3_64 = -g64 * is64 * is64 * s2 / m
-                k2 = (-g64 * is64 * s1 / m - k3_64 * mean.double()).float()
-                k3 = k3_64.float()
+            k1, k2, k3, dgamma, dbeta = ops.bn_coeffs_bwd(s1, s2, float(n * h * w), gamma.detach(), mean, invstd, ctx.train_stats)
+            if not ctx.train_stats:
+                k2 = k3 = None
         da, db = ops.act_affine_bwd(dz, y if (cfg.slope is not None or k3 is not None) else None, k1, k2, k3, cfg.slope, ctx.has_bias)
         dbias = db.float() if (ctx.has_bias and need[2]) else None
         srcs = [ConvSource(t.contiguous(), s, ps) for t, s, ps in zip(tensors, cfg.scales, cfg.shuffles)]

@@ -43,6 +43,56 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
   }
 }
 
+// Per-channel coefficient math of train/eval BatchNorm in one launch (fp64 inside), replacing dozens of [C]-sized
+// tensor ops per layer.
+//   train: mean = sum/M, var = sumsq/M - mean^2 (biased), running <- (1-mom) running + mom {mean, var*M/(M-1)}
+//   eval : mean/var = running stats
+//   a = gamma * invstd, b = beta - mean * a
+__global__ void bn_coeffs_fwd_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, double M, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float eps, float momentum, int train, float* __restrict__ running_mean,
+                                     float* __restrict__ running_var, int C, float* __restrict__ mean, float* __restrict__ invstd,
+                                     float* __restrict__ a, float* __restrict__ b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mu, var;
+  if (train) {
+    mu = sum[c] / M;
+    var = sumsq[c] / M - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    if (running_mean) {
+      const double unbiased = var * (M / (M > 1.0 ? M - 1.0 : 1.0));
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+  } else {
+    mu = (double)running_mean[c];
+    var = (double)running_var[c];
+  }
+  const double is = 1.0 / sqrt(var + (double)eps);
+  const double g = (double)gamma[c];
+  mean[c] = (float)mu;
+  invstd[c] = (float)is;
+  a[c] = (float)(g * is);
+  b[c] = (float)((double)beta[c] - mu * g * is);
+}
+
+// backward coefficients: da = (k1*dz + k2 + k3*y) * act'(y);  dgamma = s2, dbeta = s1
+//   k1 = gamma*invstd;  train: k3 = -gamma*invstd^2*s2/M, k2 = -gamma*invstd*s1/M - k3*mean;  eval: k2 = k3 = 0
+__global__ void bn_coeffs_bwd_kernel(const double* __restrict__ s1, const double* __restrict__ s2, double M, const float* __restrict__ gamma,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd, int train, int C,
+                                     float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double g = (double)gamma[c], is = (double)invstd[c];
+  const double q3 = train ? -g * is * is * s2[c] / M : 0.0;
+  k1[c] = (float)(g * is);
+  k3[c] = (float)q3;
+  k2[c] = train ? (float)(-g * is * s1[c] / M - q3 * (double)mean[c]) : 0.0f;
+  dgamma[c] = (float)s2[c];
+  dbeta[c] = (float)s1[c];
+}
+
 // z = a[c] * y + b[c] (+ resid)
 __global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ y, const float* __restrict__ a, const float* __restrict__ b,
                                                      const float* __restrict__ resid, float* __restrict__ z, int C, int HW, size_t total) {
@@ -208,6 +258,24 @@ extern "C" int slu_bn_bwd_reduce(const float* dz, const float* y, const float* m
   if (!dz || !y || !mean || !invstd || !s1 || !s2 || N <= 0 || C <= 0 || HW <= 0 || C > 65535) return SLU_EINVAL;
   const unsigned gx = cap(((size_t)N * HW + 2047) / 2048, 256);
   hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(gx, C), dim3(256), 0, slu_stream(stream), dz, y, mean, invstd, N, C, HW, s1, s2);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_bn_coeffs_fwd(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float eps,
+                                 float momentum, int train, float* running_mean, float* running_var, int C, float* mean, float* invstd,
+                                 float* a, float* b, slu_stream_t stream) {
+  if (!gamma || !beta || !mean || !invstd || !a || !b || C <= 0) return SLU_EINVAL;
+  if (train ? (!sum || !sumsq || count <= 0) : (!running_mean || !running_var)) return SLU_EINVAL;
+  hipLaunchKernelGGL(bn_coeffs_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, slu_stream(stream), sum, sumsq, count, gamma, beta, eps,
+                     momentum, train, running_mean, running_var, C, mean, invstd, a, b);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_bn_coeffs_bwd(const double* s1, const double* s2, double count, const float* gamma, const float* mean, const float* invstd,
+                                 int train, int C, float* k1, float* k2, float* k3, float* dgamma, float* dbeta, slu_stream_t stream) {
+  if (!s1 || !s2 || !gamma || !mean || !invstd || !k1 || !k2 || !k3 || !dgamma || !dbeta || C <= 0 || count <= 0) return SLU_EINVAL;
+  hipLaunchKernelGGL(bn_coeffs_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, slu_stream(stream), s1, s2, count, gamma, mean, invstd,
+                     train, C, k1, k2, k3, dgamma, dbeta);
   SLU_CHECK_LAUNCH();
 }
 

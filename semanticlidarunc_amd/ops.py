@@ -419,8 +419,8 @@ def bn_stats(y: torch.Tensor):
     """(sum f64[C], sumsq f64[C]) over (N,H,W)."""
     _req(y, "y")
     n, c, h, w = y.shape
-    s = torch.zeros(c, dtype=torch.float64, device=y.device)
-    q = torch.zeros(c, dtype=torch.float64, device=y.device)
+    sq = torch.zeros((2, c), dtype=torch.float64, device=y.device)
+    s, q = sq[0], sq[1]
     check(_lib.load().slu_bn_stats(y.data_ptr(), n, c, h * w, s.data_ptr(), q.data_ptr(), _stream()), "slu_bn_stats")
     return s, q
 
@@ -432,11 +432,38 @@ def bn_bwd_reduce(dz, y, mean, invstd):
     if dz.shape != y.shape:
         raise RuntimeError("dz / y shape mismatch")
     n, c, h, w = y.shape
-    s1 = torch.zeros(c, dtype=torch.float64, device=y.device)
-    s2 = torch.zeros(c, dtype=torch.float64, device=y.device)
+    s12 = torch.zeros((2, c), dtype=torch.float64, device=y.device)
+    s1, s2 = s12[0], s12[1]
     check(_lib.load().slu_bn_bwd_reduce(dz.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), n, c, h * w, s1.data_ptr(),
                                         s2.data_ptr(), _stream()), "slu_bn_bwd_reduce")
     return s1, s2
+
+
+def bn_coeffs_fwd(sums, count: float, gamma, beta, eps: float, momentum: float, running_mean, running_var, train: bool):
+    """(mean, invstd, a, b) [C] fp32 in one launch; in train mode the running statistics are updated in place."""
+    c = gamma.numel()
+    dev = gamma.device
+    out = torch.empty((4, c), dtype=torch.float32, device=dev)
+    s, q = (sums if sums is not None else (None, None))
+    for t, nme in ((gamma, "gamma"), (beta, "beta")):
+        _req(t, nme)
+    if running_mean is not None:
+        _req(running_mean, "running_mean")
+        _req(running_var, "running_var")
+    check(_lib.load().slu_bn_coeffs_fwd(_ptr(s), _ptr(q), float(count), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
+                                        1 if train else 0, _ptr(running_mean), _ptr(running_var), c, out[0].data_ptr(), out[1].data_ptr(),
+                                        out[2].data_ptr(), out[3].data_ptr(), _stream()), "slu_bn_coeffs_fwd")
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_coeffs_bwd(s1, s2, count: float, gamma, mean, invstd, train: bool):
+    """(k1, k2, k3, dgamma, dbeta) [C] fp32 in one launch."""
+    c = gamma.numel()
+    out = torch.empty((5, c), dtype=torch.float32, device=gamma.device)
+    check(_lib.load().slu_bn_coeffs_bwd(s1.data_ptr(), s2.data_ptr(), float(count), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                        1 if train else 0, c, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                        out[4].data_ptr(), _stream()), "slu_bn_coeffs_bwd")
+    return out[0], out[1], out[2], out[3], out[4]
 
 
 def affine(y, a=None, b=None, resid=None):
