@@ -39,26 +39,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
   const float* abase = da_t + (size_t)cob * 32 + jj;
   const float* bbase = in_t + (size_t)cib * 32 + jj;
 
+  // tap offsets in elements of in_t (wave-uniform); both operands are channel-last, so the flat pixel index is linear
+  // across rows and images and every K-step is one pointer bump
+  long long tapoff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) tapoff[t] = ((long long)(-PAD + (t / KS) * DIL) * W + (-PAD + (t % KS) * DIL)) * Cip;
+
   for (long long run = worker; run < nruns; run += nworkers) {
     const long long q0 = run * kRun;
     const long long q1 = (q0 + kRun < npairs) ? q0 + kRun : npairs;
-    for (long long q = q0; q < q1; ++q) {
-      const long long pix = 2 * q;
-      const long long n = pix / HW;
-      const int rem = (int)(pix - n * HW);
-      const int y = rem / W, x = rem - y * W;          // x even, x + 1 < W (W even)
-      const float a = abase[(size_t)(pix + hh) * Cop];
-      float b[T];
+    // position of the first pixel of the run (wave-uniform; kept in scalar registers and advanced incrementally)
+    const long long pix0 = 2 * q0;
+    const long long n0 = pix0 / HW;
+    const int rem0 = (int)(pix0 - n0 * HW);
+    int y = rem0 / W, x = rem0 - y * W;
+    const float* pa = abase + (size_t)(pix0 + hh) * Cop;
+    const float* pb = bbase + (size_t)(pix0 + hh) * Cip;
+    // four K-steps (pixel pairs) per iteration: all 4 * (1 + T) loads are issued before the first MFMA, so the
+    // L2/HBM latency of one batch hides behind the 4 * T MFMAs of the previous one across the 2 waves per SIMD
+    constexpr int U = (T >= 9) ? 2 : 4;           // 3x3: 144 accumulator registers leave room for two batches of operands
+    for (long long q = q0; q < q1; q += U) {
+      float a[U], b[U][T];
+      int yu = y, xu = x;
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int yy = y - PAD + (t / KS) * DIL, xx = x + hh - PAD + (t % KS) * DIL;
-        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const size_t idx = ok ? (size_t)(n * HW + (long long)yy * W + xx) * Cip : 0;
-        const float v = bbase[idx];
-        b[t] = ok ? v : 0.0f;
+      for (int u = 0; u < U; ++u) {
+        const bool live = q + u < q1;
+        a[u] = live ? pa[(size_t)u * 2 * Cop] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int yy = yu - PAD + (t / KS) * DIL, xx = xu + hh - PAD + (t % KS) * DIL;
+          const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+          const float v = pb[ok ? (long long)u * 2 * Cip + tapoff[t] : 0];
+          b[u][t] = ok ? v : 0.0f;
+        }
+        xu += 2;
+        if (xu >= W) { xu = 0; ++yu; if (yu >= H) yu = 0; }      // W is even: a pair never straddles a row
       }
 #pragma unroll
-      for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+      pa += (size_t)U * 2 * Cop;
+      pb += (size_t)U * 2 * Cip;
+      y = yu;
+      x = xu;
     }
   }
 
