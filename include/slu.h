@@ -49,7 +49,7 @@ const char* slu_strerror(int code);
  * PixelShuffle(2) and multiplied by a per-(n, source-channel) factor (folded Dropout2d).
  * `out` must not overlap any input (sources, resid).  Stride 1, "same" output size; kernel families (ksize,dil,pad) = (1,1,0) (3,1,1) (3,2,2) (2,2,1).
  * ------------------------------------------------------------------------------------------ */
-#define SLU_MAX_SRC 4
+#define SLU_MAX_SRC 3
 
 typedef struct slu_conv_src {
   const float* ptr;    /* [N, C, H, W]  or, when pixel_shuffle, [N, C, H/2, W/2]                */
@@ -59,7 +59,8 @@ typedef struct slu_conv_src {
   int32_t nbatch;      /* 0: the tensor holds N images; k > 0: it holds k images and output image n reads image n % k
                           (a deterministic skip tensor shared by the stacked MC passes); `scale` stays [N, C]      */
   int32_t cuse;        /* 0: every channel contributes; k > 0: only the first k channels do (the reference overwrites the
-                          last meta_channel_dim channels of a stage output: x[:, :-m], semanticFCN.py:309-313)      */
+                          last meta_channel_dim channels of a stage output: x[:, :-m], semanticFCN.py:309-313).  Only
+                          allowed on the LAST source, without pixel_shuffle                                          */
 } slu_conv_src;
 
 typedef struct slu_conv_desc {   /* HOST struct */
@@ -72,7 +73,7 @@ typedef struct slu_conv_desc {   /* HOST struct */
   const float* wpack;    /* slu_pack_conv_weight output                                          */
   const float* bias;     /* [Cout] or NULL                                                       */
   int32_t has_act;       /* 0 none; 1: leaky(v) = v > 0 ? v : slope * v (slope 0 = ReLU); 2: tanh(v);
-                            +4: apply it after bn_a/bn_b and the residual add (ResNet BasicBlock) instead of before */
+                            +4 (with 1 only): apply it after bn_a/bn_b and the residual add (ResNet BasicBlock) instead of before */
   float slope;
   const float* bn_a;     /* [Cout] or NULL (then bn_b ignored): folded eval BatchNorm            */
   const float* bn_b;
@@ -237,8 +238,10 @@ int slu_nearest_down(const float* x, float* y, int N, int C, int H, int W, int f
 int slu_space_to_depth2(const float* x, float* y, int N, int C, int H, int W, slu_stream_t stream);
 /* the same of cat(a[:, :ca], b) (a [N,Ca,H,W], b [N,Cb,H,W]) -> y [N, 4*(ca+Cb), H/2, W/2] */
 int slu_space_to_depth2_cat(const float* a, int Ca, int ca, const float* b, int Cb, float* y, int N, int H, int W, slu_stream_t stream);
-/* nn.PixelShuffle(r) of x [N,Cout*r*r,H,W] -> y [N,Cout,H*r,W*r], optionally followed by ELU(v)+1 */
-int slu_depth_to_space(const float* x, float* y, int N, int Cout, int H, int W, int r, int elu_plus_one, slu_stream_t stream);
+/* nn.PixelShuffle(r) of x [N,Cout*r*r,H,W], optionally followed by ELU(v)+1, written into channels [c_off, c_off+Cout) of
+ * y [N,Ctot,H*r,W*r] (c_off = 0, Ctot = Cout: a plain PixelShuffle; otherwise several maps share one concatenated buffer) */
+int slu_depth_to_space(const float* x, float* y, int N, int Cout, int H, int W, int r, int elu_plus_one, int c_off, int Ctot,
+                       slu_stream_t stream);
 /* out = value * softmax(score, dim=-1): score [N,1,H,W], value/out [N,C,H,W]; W <= 4096 (AttentionModule :32-38) */
 int slu_row_softmax_mul(const float* score, const float* value, float* out, int N, int C, int H, int W, slu_stream_t stream);
 

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 ABI_VERSION = 4
-MAX_SRC = 4
+MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
 
@@ -92,7 +92,7 @@ SIGNATURES = {
     "slu_nearest_down": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_space_to_depth2": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_space_to_depth2_cat": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
-    "slu_depth_to_space": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_depth_to_space": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_row_softmax_mul": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_lovasz_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_lovasz_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_size_t, c_f32p,

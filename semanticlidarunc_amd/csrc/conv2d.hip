@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
   const int n = t / a.tiles_y;
   const int x0 = tx * TW, y0 = ty * TH;
   const int mblk0 = blockIdx.y * MBLK;
+  const SrcImg im = src_images(a, n);
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         const int gy = y0 + r - PAD, gx4 = x0 - XO + 4 * c4, cg = q * CK + ci;
         const bool ok = (NIV % NT == 0 || e < NIV) && cg < a.Cin && gy >= 0 && gy < a.H && gx4 >= 0 && gx4 < a.W;
         bool ps;
-        fetch_item<GEN>(a, n, ok ? cg : 0, gy, gx4, ok, st[i], ps);
+        fetch_item<GEN>(a, im, n, ok ? cg : 0, gy, gx4, ok, st[i], ps);
         okm |= (ok ? 1u : 0u) << i;
         psm |= (ps ? 1u : 0u) << i;
       }
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         const int c = rem - r * LW;
         const int gy = y0 + r - PAD, gx = x0 + c - XO, cg = q * CK + ci;
         float v = 0.0f;
-        if (cg < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = load_input(a, n, cg, gy, gx);
+        if (cg < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = load_input(a, im, n, cg, gy, gx);
         s_in[e] = v;
       }
     }
@@ -160,6 +161,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
   //      forbids out aliasing an input), so residual loads are scheduled ahead of the stores instead of
   //      each waiting behind the previous store. ----
   const size_t plane = (size_t)a.H * a.W;
+  // activation as two leaky slopes (1.0 = identity): before BatchNorm/residual, or (has_act & 4) after them
+  const int act_kind = a.has_act & 3;
+  const bool act_late = (a.has_act & 4) != 0, act_tanh = act_kind == 2;
+  const float slope_pre = (act_kind == 1 && !act_late) ? a.slope : 1.0f;
+  const float slope_post = (act_kind == 1 && act_late) ? a.slope : 1.0f;
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
     const int ml = wm * MB + i;               // channel block inside the workgroup tile
@@ -174,17 +180,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         const bool ok = pix_ok && co < a.Cout;
         const size_t o = ok ? ((size_t)n * a.Cout + co) * plane + (size_t)gy * a.W + gx : 0;
         float v = acc[i][b][r] + s_epi[cl];
-        const int act = a.has_act & 3, late = a.has_act & 4;          // late: activation after BatchNorm + residual
-        if (!late) {
-          if (act == 1) v = v > 0.0f ? v : v * a.slope;
-          else if (act == 2) v = tanhf(v);
-        }
+        v = v > 0.0f ? v : v * slope_pre;
+        if (act_tanh) v = tanhf(v);
         v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
         if (resid) v += resid[o];
-        if (late) {
-          if (act == 1) v = v > 0.0f ? v : v * a.slope;
-          else if (act == 2) v = tanhf(v);
-        }
+        v = v > 0.0f ? v : v * slope_post;
         if (ok) out[o] = v;
       }
     }

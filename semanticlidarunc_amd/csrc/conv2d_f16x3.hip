@@ -72,6 +72,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
   const int n = t / a.tiles_y;
   const int x0 = tx * TW, y0 = ty * TH;
   const int mblk0 = blockIdx.y * MBLK;
+  const SrcImg im = src_images(a, n);
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -120,12 +121,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
         // common case: the 8 channels of this item are 8 consecutive channels of ONE plain source and the quad is
         // inside the image: one base address, constant channel stride, no per-channel selects
         const int cg0 = q * CK16 + g2 * 8;
-        const SrcPick p0 = pick_src(a, (pix_ok && cg0 < a.Cin) ? cg0 : 0);
-        fast = pix_ok && cg0 + 8 <= a.Cin && p0.cl + 8 <= p0.cc;
+        const SrcPick p0 = pick_src(a, im, (pix_ok && cg0 < a.Cin) ? cg0 : 0);
+        fast = pix_ok && cg0 + 8 <= a.Cin && p0.cl + 8 <= p0.C;
         if (fast) {
           const size_t cs = (size_t)a.H * a.W;
-          const int ns = p0.nb ? n % p0.nb : n;
-          const float* bp = p0.ptr + (((size_t)ns * p0.C + p0.cl) * a.H + gy) * a.W + gx4;
+          const float* bp = p0.ptr + (((size_t)p0.ns * p0.C + p0.cl) * a.H + gy) * a.W + gx4;
 #pragma unroll
           for (int k = 0; k < 8; ++k) st[i][k].v = *reinterpret_cast<const float4*>(bp + k * cs);
           okm[i] = 0xFFu;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
           const int cg = q * CK16 + g2 * 8 + k;
           const bool ok = pix_ok && cg < a.Cin;
           bool ps;
-          fetch_item<GEN>(a, n, ok ? cg : 0, gy, gx4, ok, st[i][k], ps);
+          fetch_item<GEN>(a, im, n, ok ? cg : 0, gy, gx4, ok, st[i][k], ps);
           okm[i] |= (ok ? 1u : 0u) << k;
           psm[i] |= (ps ? 1u : 0u) << k;
         }
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int cg = q * CK16 + g2 * 8 + k;
-          x[k] = (cg < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? load_input(a, n, cg, gy, gx) : 0.0f;
+          x[k] = (cg < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? load_input(a, im, n, cg, gy, gx) : 0.0f;
         }
         uint4 hi, lo;
         split8(x, hi, lo);
@@ -256,6 +256,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
   }
 
   // ---- epilogue (identical to the fp32 kernel: the D fragment layout does not depend on the input dtype) ----
+  // activation as two leaky slopes (1.0 = identity): before BatchNorm/residual, or (has_act & 4) after them
+  const int act_kind = a.has_act & 3;
+  const bool act_late = (a.has_act & 4) != 0, act_tanh = act_kind == 2;
+  const float slope_pre = (act_kind == 1 && !act_late) ? a.slope : 1.0f;
+  const float slope_post = (act_kind == 1 && act_late) ? a.slope : 1.0f;
   const size_t plane = (size_t)a.H * a.W;
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
@@ -271,17 +276,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 1 : 2) void conv_f1
         const bool ok = pix_ok && co < a.Cout;
         const size_t o = ok ? ((size_t)n * a.Cout + co) * plane + (size_t)gy * a.W + gx : 0;
         float v = acc[i][b][r] + s_epi[cl];
-        const int act = a.has_act & 3, late = a.has_act & 4;          // late: activation after BatchNorm + residual
-        if (!late) {
-          if (act == 1) v = v > 0.0f ? v : v * a.slope;
-          else if (act == 2) v = tanhf(v);
-        }
+        v = v > 0.0f ? v : v * slope_pre;
+        if (act_tanh) v = tanhf(v);
         v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
         if (resid) v += resid[o];
-        if (late) {
-          if (act == 1) v = v > 0.0f ? v : v * a.slope;
-          else if (act == 2) v = tanhf(v);
-        }
+        v = v > 0.0f ? v : v * slope_post;
         if (ok) out[o] = v;
       }
     }
@@ -341,6 +340,13 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
     hw[b] = pix - img[b] * HW;
   }
 
+  // image of every source tensor read by each pixel block (batch-broadcast sources): resolved once, not per K-step
+  int simg[NBW][SLU_MAX_SRC];
+#pragma unroll
+  for (int b = 0; b < NBW; ++b)
+#pragma unroll
+    for (int s = 0; s < SLU_MAX_SRC; ++s) simg[b][s] = (s < a.nsrc && a.src[s].nb) ? (int)img[b] % a.src[s].nb : (int)img[b];
+
   const uint4* wsrc = reinterpret_cast<const uint4*>(a.wpack);
   const int nq = (a.nchunks + KSPC - 1) / KSPC;         // a.nchunks counts 16-channel groups
   int src = 0;                                          // source that holds channel group `g16` (sources are 16-aligned)
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
         const int cl0 = c0 - S.cbeg + 8 * hh;           // this lane half's first channel inside the source
 #pragma unroll
         for (int b = 0; b < NBW; ++b) {
-          const long long is_ = S.nb ? img[b] % S.nb : img[b];
+          const int is_ = s_ == 0 ? simg[b][0] : (s_ == 1 ? simg[b][1] : simg[b][2]);
           const size_t base = ((size_t)is_ * S.C + cl0) * HW + hw[b];
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
@@ -418,6 +424,11 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
     }
   }
 
+  // activation as two leaky slopes (1.0 = identity): before BatchNorm/residual, or (has_act & 4) after them
+  const int act_kind = a.has_act & 3;
+  const bool act_late = (a.has_act & 4) != 0, act_tanh = act_kind == 2;
+  const float slope_pre = (act_kind == 1 && !act_late) ? a.slope : 1.0f;
+  const float slope_post = (act_kind == 1 && act_late) ? a.slope : 1.0f;
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -428,17 +439,11 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
         const bool ok = live[b] && co < a.Cout;
         const size_t o = ok ? ((size_t)img[b] * a.Cout + co) * HW + hw[b] : 0;
         float v = acc[i][b][r] + s_epi[co];
-        const int act = a.has_act & 3, late = a.has_act & 4;          // late: activation after BatchNorm + residual
-        if (!late) {
-          if (act == 1) v = v > 0.0f ? v : v * a.slope;
-          else if (act == 2) v = tanhf(v);
-        }
+        v = v > 0.0f ? v : v * slope_pre;
+        if (act_tanh) v = tanhf(v);
         v = v * s_epi[MB * 32 + co] + s_epi[2 * MB * 32 + co];
         if (resid) v += resid[o];
-        if (late) {
-          if (act == 1) v = v > 0.0f ? v : v * a.slope;
-          else if (act == 2) v = tanhf(v);
-        }
+        v = v > 0.0f ? v : v * slope_post;
         if (ok) out[o] = v;
       }
 }

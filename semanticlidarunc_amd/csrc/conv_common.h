@@ -40,20 +40,31 @@ struct ConvArgs {
 struct SrcPick {
   const float* ptr;
   const float* scale;
-  int C, cl, ps, nb, cc;   // cc = channels this source contributes (<= C when only a prefix is used)
+  int C, cl, ps, ns;       // ns = image of the source tensor this workgroup reads
 };
-__device__ __forceinline__ SrcPick pick_src(const ConvArgs& a, int cg) {
-  SrcPick p{a.src[0].ptr, a.src[0].scale, a.src[0].C, cg, a.src[0].ps, a.src[0].nb, a.src[0].ccount};
+// Source image per source for output image n (wave-uniform; computed once per workgroup, not per element).
+struct SrcImg {
+  int v[SLU_MAX_SRC];
+};
+__device__ __forceinline__ SrcImg src_images(const ConvArgs& a, int n) {
+  SrcImg r;
+#pragma unroll
+  for (int s = 0; s < SLU_MAX_SRC; ++s) r.v[s] = (s < a.nsrc && a.src[s].nb) ? n % a.src[s].nb : n;
+  return r;
+}
+
+__device__ __forceinline__ SrcPick pick_src(const ConvArgs& a, const SrcImg& im, int cg) {
+  SrcPick p{a.src[0].ptr, a.src[0].scale, a.src[0].C, cg, a.src[0].ps, im.v[0]};
 #pragma unroll
   for (int s = 1; s < SLU_MAX_SRC; ++s)
-    if (s < a.nsrc && cg >= a.src[s].cbeg) p = SrcPick{a.src[s].ptr, a.src[s].scale, a.src[s].C, cg - a.src[s].cbeg, a.src[s].ps, a.src[s].nb, a.src[s].ccount};
+    if (s < a.nsrc && cg >= a.src[s].cbeg) p = SrcPick{a.src[s].ptr, a.src[s].scale, a.src[s].C, cg - a.src[s].cbeg, a.src[s].ps, im.v[s]};
   return p;
 }
 
 // one element (any W): used only when W % 4 != 0
-__device__ __forceinline__ float load_input(const ConvArgs& a, int n, int cg, int gy, int gx) {
-  const SrcPick p = pick_src(a, cg);
-  const int ns = p.nb ? n % p.nb : n;           // image of the source tensor
+__device__ __forceinline__ float load_input(const ConvArgs& a, const SrcImg& im, int n, int cg, int gy, int gx) {
+  const SrcPick p = pick_src(a, im, cg);
+  const int ns = p.ns;                          // image of the source tensor
   float v;
   int cs;
   if (!p.ps) {
@@ -83,9 +94,9 @@ struct Item<true> {
 
 // gx4 % 4 == 0, W % 4 == 0.  `ok` false -> address clamped to element 0 of the source (always mapped).
 template <bool GEN>
-__device__ __forceinline__ void fetch_item(const ConvArgs& a, int n, int cg, int gy, int gx4, bool ok, Item<GEN>& it, bool& is_ps) {
-  const SrcPick p = pick_src(a, cg);
-  const int ns = p.nb ? n % p.nb : n;           // image of the source tensor (multipliers stay per output image)
+__device__ __forceinline__ void fetch_item(const ConvArgs& a, const SrcImg& im, int n, int cg, int gy, int gx4, bool ok, Item<GEN>& it, bool& is_ps) {
+  const SrcPick p = pick_src(a, im, cg);
+  const int ns = p.ns;                          // image of the source tensor (multipliers stay per output image)
   if constexpr (!GEN) {
     const size_t idx = ok ? (((size_t)ns * p.C + p.cl) * a.H + gy) * a.W + gx4 : 0;
     it.v = *reinterpret_cast<const float4*>(p.ptr + idx);
@@ -163,7 +174,8 @@ inline int fill_args(const slu_conv_desc* d, ConvArgs& a) {
     a.src[s].ps = S.pixel_shuffle ? 1 : 0;
     a.src[s].cbeg = c;
     a.src[s].ccount = S.pixel_shuffle ? S.C / 4 : (S.cuse > 0 ? S.cuse : S.C);
-    if (S.cuse < 0 || S.cuse > S.C || (S.cuse && S.pixel_shuffle)) return SLU_EINVAL;
+    // a channel prefix (cuse) is only honoured on the LAST source: the kernels bound it by Cin, not per source
+    if (S.cuse < 0 || S.cuse > S.C || (S.cuse && (S.pixel_shuffle || s != d->nsrc - 1))) return SLU_EINVAL;
     a.src[s].nb = S.nbatch > 0 ? S.nbatch : 0;
     c += a.src[s].ccount;
   }
@@ -175,6 +187,7 @@ inline int fill_args(const slu_conv_desc* d, ConvArgs& a) {
   a.nchunks = (d->Cin + d->ck - 1) / d->ck;
   a.nmblk = (d->Cout + 31) / 32;
   a.wpack = d->wpack; a.bias = d->bias; a.bn_a = d->bn_a; a.bn_b = d->bn_b; a.resid = d->resid; a.out = d->out;
+  if (d->has_act < 0 || d->has_act > 5 || d->has_act == 3 || d->has_act == 4) return SLU_EINVAL;   // tanh has no late form
   a.slope = d->slope; a.has_act = d->has_act;
   a.vec = (d->W % 4 == 0);
   a.gen = 0;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void space_to_depth2_cat_kernel(const float* _
 
 // nn.PixelShuffle(r) (+ optional ELU(alpha=1) + 1): y[n,c,h*r+i,w*r+j] = f(x[n, c*r*r + i*r + j, h, w])
 __global__ __launch_bounds__(256) void depth_to_space_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int Cout, int H, int W, int r,
-                                                             int elu_plus_one) {
+                                                             int elu_plus_one, int c_off, int Ctot) {
   const int OH = H * r, OW = W * r;
   const size_t total = (size_t)N * Cout * OH * OW;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void depth_to_space_kernel(const float* __rest
     const int cs = c * r * r + (oy % r) * r + (ox % r);
     float v = x[((n * (size_t)Cout * r * r + cs) * H + oy / r) * W + ox / r];
     if (elu_plus_one) v = (v > 0.0f ? v : expm1f(v)) + 1.0f;
-    y[e] = v;
+    y[((n * Ctot + c_off + c) * OH + oy) * (size_t)OW + ox] = v;
   }
 }
 
@@ -163,10 +163,11 @@ extern "C" int slu_space_to_depth2_cat(const float* a, int Ca, int ca, const flo
   SLU_CHECK_LAUNCH();
 }
 
-extern "C" int slu_depth_to_space(const float* x, float* y, int N, int Cout, int H, int W, int r, int elu_plus_one, slu_stream_t stream) {
-  if (!x || !y || N <= 0 || Cout <= 0 || H <= 0 || W <= 0 || r <= 0) return SLU_EINVAL;
+extern "C" int slu_depth_to_space(const float* x, float* y, int N, int Cout, int H, int W, int r, int elu_plus_one, int c_off, int Ctot,
+                                  slu_stream_t stream) {
+  if (!x || !y || N <= 0 || Cout <= 0 || H <= 0 || W <= 0 || r <= 0 || c_off < 0 || c_off + Cout > Ctot) return SLU_EINVAL;
   const size_t total = (size_t)N * Cout * H * W * r * r;
-  hipLaunchKernelGGL(depth_to_space_kernel, dim3(cap((total + 255) / 256, 16384)), dim3(256), 0, slu_stream(stream), x, y, N, Cout, H, W, r, elu_plus_one);
+  hipLaunchKernelGGL(depth_to_space_kernel, dim3(cap((total + 255) / 256, 16384)), dim3(256), 0, slu_stream(stream), x, y, N, Cout, H, W, r, elu_plus_one, c_off, Ctot);
   SLU_CHECK_LAUNCH();
 }
 

@@ -189,7 +189,7 @@ class SemanticNetworkWithFPN(nn.Module):
         p = self._prep(name, make, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
         return ops.conv2d_fused([ConvSource(s2d)], p.wpack, p.cout, 2, 1, 1, bias=p.bias, precision=p.precision, act="relu")
 
-    def _convT_eq_stride(self, name, ct: nn.ConvTranspose2d, x):
+    def _convT_eq_stride(self, name, ct: nn.ConvTranspose2d, x, out=None, c_off=0):
         s = ct.stride[0]
 
         def make():
@@ -200,7 +200,7 @@ class SemanticNetworkWithFPN(nn.Module):
             return wc, b, 1, 1, 0
         p = self._prep(name, make, ct.weight, ct.bias)
         y = ops.conv2d_fused([ConvSource(x)], p.wpack, p.cout, 1, 1, 0, bias=p.bias, precision=p.precision, act="none")
-        return ops.depth_to_space(y, s)
+        return ops.depth_to_space(y, s, False, out, c_off)
 
     def _convT_k4s2p1(self, name, ct: nn.ConvTranspose2d, x, elu_plus_one):
         def make():
@@ -278,10 +278,13 @@ class SemanticNetworkWithFPN(nn.Module):
         if self.attention:
             f4, f3 = self._attend("att4", self.attention4, f4), self._attend("att3", self.attention3, f3)
             f2, f1 = self._attend("att2", self.attention2, f2), self._attend("att1", self.attention1, f1)
-        u4 = self._convT_eq_stride("up4", self.upsample_layer_x4, f4)
-        u3 = self._convT_eq_stride("up3", self.upsample_layer_x3, f3)
-        u2 = self._convT_eq_stride("up2", self.upsample_layer_x2, f2)
+        # the three up-sampled maps land in channel slices of one buffer: cat([x1, x2, x3, x4]) is read as 2 sources
+        c2, c3, c4 = (m.out_channels for m in (self.upsample_layer_x2, self.upsample_layer_x3, self.upsample_layer_x4))
+        ups = torch.empty((f1.shape[0], c2 + c3 + c4, f1.shape[2], f1.shape[3]), dtype=torch.float32, device=f1.device)
+        self._convT_eq_stride("up2", self.upsample_layer_x2, f2, ups, 0)
+        self._convT_eq_stride("up3", self.upsample_layer_x3, f3, ups, c2)
+        self._convT_eq_stride("up4", self.upsample_layer_x4, f4, ups, c2 + c3)
         d = self.decoder_semantic
-        y = self._conv("dec0", d[0], d[1], [ConvSource(f1), ConvSource(u2), ConvSource(u3), ConvSource(u4)])
+        y = self._conv("dec0", d[0], d[1], [ConvSource(f1), ConvSource(ups)])
         y = self._conv("dec1", d[3], d[4], [ConvSource(y)])
         return self._convT_k4s2p1("dec_out", d[6], y, elu_plus_one=True)

@@ -619,16 +619,23 @@ def space_to_depth2_cat(a, ca: int, b):
     return y
 
 
-def depth_to_space(x, r: int, elu_plus_one: bool = False):
-    """nn.PixelShuffle(r), optionally followed by ELU(v) + 1."""
+def depth_to_space(x, r: int, elu_plus_one: bool = False, out: Optional[torch.Tensor] = None, c_off: int = 0):
+    """nn.PixelShuffle(r), optionally followed by ELU(v) + 1.  With `out` [N,Ctot,H*r,W*r] the result is written into its
+    channels [c_off, c_off + C/r^2) (several up-sampled maps sharing one concatenated buffer)."""
     _req(x, "x")
     n, c, h, w = x.shape
     if c % (r * r):
         raise RuntimeError("depth_to_space: C must be a multiple of r*r")
-    y = torch.empty((n, c // (r * r), h * r, w * r), dtype=torch.float32, device=x.device)
-    check(_lib.load().slu_depth_to_space(x.data_ptr(), y.data_ptr(), n, c // (r * r), h, w, int(r), 1 if elu_plus_one else 0, _stream()),
-          "slu_depth_to_space")
-    return y
+    cout = c // (r * r)
+    if out is None:
+        out = torch.empty((n, cout, h * r, w * r), dtype=torch.float32, device=x.device)
+    else:
+        _req(out, "out")
+        if out.shape[0] != n or tuple(out.shape[2:]) != (h * r, w * r) or c_off < 0 or c_off + cout > out.shape[1]:
+            raise RuntimeError("depth_to_space: `out` does not fit")
+    check(_lib.load().slu_depth_to_space(x.data_ptr(), out.data_ptr(), n, cout, h, w, int(r), 1 if elu_plus_one else 0, int(c_off),
+                                         out.shape[1], _stream()), "slu_depth_to_space")
+    return out
 
 
 def row_softmax_mul(score, value):
