@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 4
+#define SLU_ABI_VERSION 5
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -244,6 +244,49 @@ int slu_depth_to_space(const float* x, float* y, int N, int Cout, int H, int W, 
                        slu_stream_t stream);
 /* out = value * softmax(score, dim=-1): score [N,1,H,W], value/out [N,C,H,W]; W <= 4096 (AttentionModule :32-38) */
 int slu_row_softmax_mul(const float* score, const float* value, float* out, int N, int C, int H, int W, slu_stream_t stream);
+
+/* ---- fp16 channel-blocked ("h8") inference path: BASELINE.json configs[2],[4] (half-precision storage, fp32 accumulate) -------
+ * Activation layout: x[N][G = ceil(C/8)][H][W][8] fp16, pad channels = 0, base pointers 16-byte aligned.
+ * Replaces the same reference arithmetic as slu_conv2d_fwd (SalsaNext.py:25-39,73-109,142-170,197-215) with fp16 operands. */
+typedef struct slu_h8_src {
+  const void* ptr;     /* h8 tensor [nimg][G][H][W][8]                                                              */
+  const float* scale;  /* [N][8 G] fp32 multiplier per (output image, channel) (Dropout2d), or NULL; 16-byte aligned  */
+  int32_t G;           /* channel blocks                                                                             */
+  int32_t nbatch;      /* 0: nimg = N; k > 0: the tensor holds k images, output image n reads image n % k            */
+} slu_h8_src;
+
+typedef struct slu_conv_h8_desc {   /* HOST struct */
+  slu_h8_src src[SLU_MAX_SRC];  /* concatenated along channels, block-wise (torch.cat(dim=1) of 8-aligned tensors)   */
+  int32_t nsrc;
+  int32_t N, H, W, Cout, ksize, dil, pad;
+  const void* wpack;     /* slu_pack_conv_weight_h8 output                                                           */
+  const float* bias;     /* [Cout] fp32 or NULL                                                                      */
+  int32_t has_act;       /* 0 none; 1: leaky(v) = v > 0 ? v : slope * v                                              */
+  float slope;
+  const float* bn_a;     /* [Cout] fp32 or NULL: folded eval BatchNorm                                               */
+  const float* bn_b;
+  const void* resid;     /* h8 [N][ceil(Cout/8)][H][W][8] or NULL                                                    */
+  void* out;             /* h8 [N][ceil(Cout/8)][H][W][8], or fp32 [N][Cout][H][W] when out_f32_nchw                  */
+  int32_t out_f32_nchw;  /* 1: the logits head (SalsaNext.py:213) keeps the reference's fp32 NCHW output             */
+} slu_conv_h8_desc;
+
+size_t slu_packed_weight_bytes_h8(int cout, int cin, int ksize);
+/* w: OIHW fp32 [cout][cin][k][k] (cin = real channels of the concatenated input; only the LAST source may be padded) */
+int slu_pack_conv_weight_h8(const float* w, int cout, int cin, int ksize, void* out, slu_stream_t stream);
+/* out = [resid +] bn_a * act(conv(cat(src * scale)) + bias) + bn_b, rounded to fp16 once.
+ * Families: (k,dil,pad) = (1,1,0), (3,1,1), (3,2,2), (2,2,1) as in slu_conv2d_fwd. */
+int slu_conv2d_h8_fwd(const slu_conv_h8_desc* desc, slu_stream_t stream);
+/* name of the kernel instantiation the call above launches (as rocprofv3 prints it); host only, no launch */
+int slu_conv2d_h8_kernel_name(const slu_conv_h8_desc* desc, char* buf, size_t n);
+/* fp32 NCHW <-> h8 (set_model_inputs' tensor on the way in, utils/inputs.py:4-34; scale [N][C] optional) */
+int slu_nchw_to_h8(const float* x, const float* scale, void* y, int N, int C, int H, int W, slu_stream_t stream);
+int slu_h8_to_nchw(const void* x, float* y, int N, int C, int H, int W, slu_stream_t stream);
+/* AvgPool2d(3, 2, 1) of x * scale[n][c] (SalsaNext.py:69,98-101); in_batch > 0: x holds in_batch images shared by all n */
+int slu_avgpool3s2_h8(const void* x, const float* scale, void* y, int N, int in_batch, int G, int H, int W, slu_stream_t stream);
+/* nn.PixelShuffle(2) (SalsaNext.py:143): y[n][c][2h+i][2w+j] = x[n][4c+2i+j][h][w] * scale_in[n][4c+2i+j] * scale_out[n][c];
+ * x: h8 with Gin blocks at HxW; y: h8 with ceil(2 Gin / 8) blocks at 2Hx2W; scales fp32 [N][8 Gin] / [N][2 Gin] or NULL */
+int slu_pixel_shuffle_h8(const void* x, const float* scale_in, const float* scale_out, void* y, int N, int Gin, int H, int W,
+                         slu_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -38,6 +38,24 @@ class ConvDesc(C.Structure):
         ("bn_a", C.c_void_p), ("bn_b", C.c_void_p),
         ("resid", C.c_void_p), ("out", C.c_void_p),
         ("precision", C.c_int32),
+    ]
+
+
+class H8Src(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("G", C.c_int32), ("nbatch", C.c_int32)]
+
+
+class ConvH8Desc(C.Structure):
+    _fields_ = [
+        ("src", H8Src * MAX_SRC),
+        ("nsrc", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32),
+        ("ksize", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
+        ("wpack", C.c_void_p), ("bias", C.c_void_p),
+        ("has_act", C.c_int32), ("slope", C.c_float),
+        ("bn_a", C.c_void_p), ("bn_b", C.c_void_p),
+        ("resid", C.c_void_p), ("out", C.c_void_p),
+        ("out_f32_nchw", C.c_int32),
     ]
 
 
@@ -94,6 +112,14 @@ SIGNATURES = {
     "slu_space_to_depth2_cat": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_depth_to_space": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_row_softmax_mul": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_packed_weight_bytes_h8": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "slu_pack_conv_weight_h8": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "slu_conv2d_h8_fwd": (C.c_int, [C.POINTER(ConvH8Desc), c_stream]),
+    "slu_conv2d_h8_kernel_name": (C.c_int, [C.POINTER(ConvH8Desc), C.c_char_p, C.c_size_t]),
+    "slu_nchw_to_h8": (C.c_int, [c_f32p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_h8_to_nchw": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_avgpool3s2_h8": (C.c_int, [C.c_void_p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_pixel_shuffle_h8": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_lovasz_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_lovasz_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_size_t, c_f32p,
                                  c_f32p, c_f32p, c_stream]),

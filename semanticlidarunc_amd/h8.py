@@ -1,0 +1,181 @@
+"""Checked wrappers of the fp16 channel-blocked ("h8") inference kernels (include/slu.h, section "h8").
+
+An h8 activation is a contiguous ``torch.float16`` tensor of shape ``[N, G, H, W, 8]`` holding channels
+``8g .. 8g+7`` of pixel (h, w) in its last axis (pad channels are zero).  All arithmetic happens in the HIP
+kernels (fp16 operands, fp32 accumulate / epilogue); torch only owns the memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional, Sequence
+
+import torch
+
+from . import _lib, ops
+from ._lib import ConvH8Desc, check
+from .ops import _ptr, _req, _stream
+
+
+class H8Source(NamedTuple):
+    tensor: torch.Tensor                    # [nimg, G, H, W, 8] fp16
+    scale: Optional[torch.Tensor] = None    # [N, 8 G] fp32 multiplier (folded Dropout2d) or None
+    nbatch: int = 0                         # > 0: tensor holds nbatch images, output image n reads image n % nbatch
+
+
+def _req_h8(t: torch.Tensor, name: str) -> torch.Tensor:
+    _req(t, name, torch.float16)
+    if t.dim() != 5 or t.shape[4] != 8:
+        raise RuntimeError(f"{name}: expected an h8 tensor [N, G, H, W, 8], got {tuple(t.shape)}")
+    return t
+
+
+def to_h8(x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 NCHW -> h8 (channels padded to a multiple of 8 with zeros), optionally times scale[n, c]."""
+    _req(x, "x")
+    if x.dim() != 4:
+        raise RuntimeError(f"x: expected NCHW, got {tuple(x.shape)}")
+    n, c, h, w = x.shape
+    if scale is not None:
+        _req(scale, "scale")
+        if tuple(scale.shape) != (n, c):
+            raise RuntimeError(f"scale: expected {(n, c)}, got {tuple(scale.shape)}")
+    y = torch.empty((n, (c + 7) // 8, h, w, 8), dtype=torch.float16, device=x.device)
+    check(_lib.load().slu_nchw_to_h8(x.data_ptr(), _ptr(scale), y.data_ptr(), n, c, h, w, _stream()), "slu_nchw_to_h8")
+    return y
+
+
+def from_h8(x: torch.Tensor, channels: Optional[int] = None) -> torch.Tensor:
+    """h8 -> fp32 NCHW with `channels` channels (default 8 G)."""
+    _req_h8(x, "x")
+    n, g, h, w, _ = x.shape
+    c = 8 * g if channels is None else int(channels)
+    if not 8 * (g - 1) < c <= 8 * g:
+        raise RuntimeError(f"from_h8: {c} channels do not fit {g} blocks")
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_h8_to_nchw(x.data_ptr(), y.data_ptr(), n, c, h, w, _stream()), "slu_h8_to_nchw")
+    return y
+
+
+def pack_conv_weight_h8(weight: torch.Tensor) -> torch.Tensor:
+    """OIHW fp32 weight -> fp16 MFMA A-fragment image (re-run after every weight update)."""
+    _req(weight, "weight")
+    if weight.dim() != 4 or weight.shape[2] != weight.shape[3]:
+        raise RuntimeError(f"weight: expected [Cout,Cin,k,k], got {tuple(weight.shape)}")
+    lib = _lib.load()
+    cout, cin, ks, _ = weight.shape
+    nbytes = lib.slu_packed_weight_bytes_h8(cout, cin, ks)
+    if nbytes == 0:
+        raise RuntimeError("pack_conv_weight_h8: unsupported weight shape")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    check(lib.slu_pack_conv_weight_h8(weight.data_ptr(), cout, cin, ks, out.data_ptr(), _stream()), "slu_pack_conv_weight_h8")
+    return out
+
+
+def conv2d_h8(srcs: Sequence[H8Source], wpack: torch.Tensor, cin: int, cout: int, ksize: int, dil: int, pad: int,
+              bias: Optional[torch.Tensor] = None, slope: Optional[float] = None,
+              bn_a: Optional[torch.Tensor] = None, bn_b: Optional[torch.Tensor] = None,
+              resid: Optional[torch.Tensor] = None, out_f32_nchw: bool = False) -> torch.Tensor:
+    """out = [resid +] bn_a * leaky(conv(cat(srcs * scale)) + bias) + bn_b  (slu_conv2d_h8_fwd).
+    `cin` = real input channels the weight was packed with (only the last source may carry pad channels)."""
+    lib = _lib.load()
+    if not 1 <= len(srcs) <= _lib.MAX_SRC:
+        raise RuntimeError(f"conv2d_h8: 1..{_lib.MAX_SRC} sources supported, got {len(srcs)}")
+    d = ConvH8Desc()
+    n = h = w = None
+    gin = 0
+    keep = []
+    for i, s in enumerate(srcs):
+        t = _req_h8(s.tensor, f"src[{i}]")
+        sn, sg, sh, sw, _ = t.shape
+        if s.nbatch:
+            if i == 0 or sn != s.nbatch or n % sn:
+                raise RuntimeError(f"src[{i}]: a batch-broadcast source must follow a full-batch source and divide N")
+            sn = n
+        if n is None:
+            n, h, w = sn, sh, sw
+        elif (sn, sh, sw) != (n, h, w):
+            raise RuntimeError(f"src[{i}]: spatial/batch size {(sn, sh, sw)} != {(n, h, w)}")
+        if s.scale is not None:
+            _req(s.scale, f"src[{i}].scale")
+            if tuple(s.scale.shape) != (n, 8 * sg):
+                raise RuntimeError(f"src[{i}].scale: expected {(n, 8 * sg)}, got {tuple(s.scale.shape)}")
+        d.src[i].ptr, d.src[i].scale, d.src[i].G, d.src[i].nbatch = t.data_ptr(), _ptr(s.scale), sg, int(s.nbatch)
+        gin += sg
+        keep.append(t)
+    if not 8 * (gin - 1) < cin <= 8 * gin:
+        raise RuntimeError(f"conv2d_h8: cin={cin} does not match {gin} input blocks")
+    _req(wpack, "wpack", torch.uint8)
+    if wpack.numel() != lib.slu_packed_weight_bytes_h8(cout, cin, ksize):
+        raise RuntimeError(f"wpack: {wpack.numel()} bytes does not match Cout={cout} Cin={cin} k={ksize} (h8)")
+    for t, nme in ((bias, "bias"), (bn_a, "bn_a"), (bn_b, "bn_b")):
+        if t is not None:
+            _req(t, nme)
+            if t.numel() != cout:
+                raise RuntimeError(f"{nme}: expected {cout} elements, got {t.numel()}")
+    if (bn_a is None) != (bn_b is None):
+        raise RuntimeError("bn_a and bn_b must be given together")
+    gout = (cout + 7) // 8
+    if out_f32_nchw:
+        if resid is not None:
+            raise RuntimeError("conv2d_h8: no residual on the fp32 NCHW output form")
+        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=keep[0].device)
+    else:
+        out = torch.empty((n, gout, h, w, 8), dtype=torch.float16, device=keep[0].device)
+    if resid is not None:
+        _req_h8(resid, "resid")
+        if tuple(resid.shape) != (n, gout, h, w, 8):
+            raise RuntimeError(f"resid: expected {(n, gout, h, w, 8)}, got {tuple(resid.shape)}")
+    d.nsrc = len(srcs)
+    d.N, d.H, d.W, d.Cout = n, h, w, cout
+    d.ksize, d.dil, d.pad = ksize, dil, pad
+    d.wpack, d.bias = wpack.data_ptr(), _ptr(bias)
+    d.has_act, d.slope = (0, 0.0) if slope is None else (1, float(slope))
+    d.bn_a, d.bn_b, d.resid, d.out = _ptr(bn_a), _ptr(bn_b), _ptr(resid), out.data_ptr()
+    d.out_f32_nchw = 1 if out_f32_nchw else 0
+    if ops.TIMING is None:
+        check(lib.slu_conv2d_h8_fwd(C.byref(d), _stream()), "slu_conv2d_h8_fwd")
+        return out
+    # measurement mode (bench.py): HIP events on the launch stream around this one kernel
+    buf = C.create_string_buffer(96)
+    check(lib.slu_conv2d_h8_kernel_name(C.byref(d), buf, 96), "slu_conv2d_h8_kernel_name")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.slu_conv2d_h8_fwd(C.byref(d), _stream()), "slu_conv2d_h8_fwd")
+    e1.record()
+    flops = 2.0 * cin * cout * ksize * ksize * n * h * w
+    nbytes = n * h * w * (2.0 * cin + (4.0 if out_f32_nchw else 2.0) * cout) + 2.0 * cout * cin * ksize * ksize
+    ops.TIMING.append((buf.value.decode(), flops, nbytes, e0, e1))
+    ops.TIMING_TAGS.append(f"N{n} {cin}->{cout} k{ksize}d{dil} {h}x{w}")
+    return out
+
+
+def avgpool3s2_h8(x: torch.Tensor, scale: Optional[torch.Tensor] = None, n_out: Optional[int] = None) -> torch.Tensor:
+    """AvgPool2d(3, 2, 1) of x[n % B] * scale[n] for n < n_out (n_out = B unless x is shared by stacked MC passes)."""
+    _req_h8(x, "x")
+    b, g, h, w, _ = x.shape
+    n = b if n_out is None else int(n_out)
+    if n % b:
+        raise RuntimeError("avgpool3s2_h8: n_out must be a multiple of the input batch")
+    if scale is not None:
+        _req(scale, "scale")
+        if tuple(scale.shape) != (n, 8 * g):
+            raise RuntimeError(f"scale: expected {(n, 8 * g)}, got {tuple(scale.shape)}")
+    y = torch.empty((n, g, (h + 1) // 2, (w + 1) // 2, 8), dtype=torch.float16, device=x.device)
+    check(_lib.load().slu_avgpool3s2_h8(x.data_ptr(), _ptr(scale), y.data_ptr(), n, 0 if n == b else b, g, h, w, _stream()),
+          "slu_avgpool3s2_h8")
+    return y
+
+
+def pixel_shuffle_h8(x: torch.Tensor, scale_in: Optional[torch.Tensor] = None, scale_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.PixelShuffle(2) of x * scale_in[n, c_in], times scale_out[n, c_out] (both Dropout2d multipliers around it)."""
+    _req_h8(x, "x")
+    n, g, h, w, _ = x.shape
+    for t, nme, c in ((scale_in, "scale_in", 8 * g), (scale_out, "scale_out", 2 * g)):
+        if t is not None:
+            _req(t, nme)
+            if tuple(t.shape) != (n, c):
+                raise RuntimeError(f"{nme}: expected {(n, c)}, got {tuple(t.shape)}")
+    y = torch.empty((n, (2 * g + 7) // 8, 2 * h, 2 * w, 8), dtype=torch.float16, device=x.device)
+    check(_lib.load().slu_pixel_shuffle_h8(x.data_ptr(), _ptr(scale_in), _ptr(scale_out), y.data_ptr(), n, g, h, w, _stream()),
+          "slu_pixel_shuffle_h8")
+    return y

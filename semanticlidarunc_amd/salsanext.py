@@ -21,22 +21,25 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import h8, ops
 from .autograd import AvgPoolFn, ConvLayerFn, LayerCfg
 from .ops import ConvSource
 
 _SLOPE = 0.01  # nn.LeakyReLU() default used throughout the reference model
 
 # Multiply precision of the fused inference convs: "fp32" = exact fp32 MFMA; "f16x3" = split-fp16 (three f16
-# MFMAs per K-step, ~2^-22 relative product error, 5x fewer matrix-core cycles).  Training / autograd always
-# runs the exact kernels.  Override per process with SLU_CONV_PRECISION or set_conv_precision().
+# MFMAs per K-step, ~2^-22 relative product error, 5x fewer matrix-core cycles); "f16" = fp16 storage in channel
+# blocks of 8 + one f16 MFMA per K-step with fp32 accumulation (BASELINE.json configs[2],[4]: half-precision
+# inference, logits within 1e-3 of the fp32 reference).  Training / autograd always runs the exact kernels.
+# Override per process with SLU_CONV_PRECISION or set_conv_precision().
+CONV_PRECISIONS = ("fp32", "f16x3", "f16")
 _CONV_PRECISION = os.environ.get("SLU_CONV_PRECISION", "fp32")
 
 
 def set_conv_precision(precision: str) -> None:
     global _CONV_PRECISION
-    if precision not in ops.PRECISIONS:
-        raise ValueError(f"unknown conv precision {precision!r}; choose from {sorted(ops.PRECISIONS)}")
+    if precision not in CONV_PRECISIONS:
+        raise ValueError(f"unknown conv precision {precision!r}; choose from {CONV_PRECISIONS}")
     _CONV_PRECISION = precision
 
 
@@ -48,12 +51,13 @@ class _Prepared:
     """Device-side derived constants of one conv (+ its BatchNorm): the MFMA-ordered weight image and
     the folded BN affine.  Rebuilt lazily whenever the owning parameters/buffers change."""
 
-    __slots__ = ("key", "wpack", "bn_key", "bn_a", "bn_b", "dgrad", "key16", "wpack16")
+    __slots__ = ("key", "wpack", "bn_key", "bn_a", "bn_b", "dgrad", "key16", "wpack16", "key8", "wpack8")
 
     def __init__(self):
         self.key = self.bn_key = None
         self.wpack = self.bn_a = self.bn_b = None
         self.key16 = self.wpack16 = None
+        self.key8 = self.wpack8 = None
         self.dgrad = {}          # packed data-gradient weights, keyed by the weight version
 
 
@@ -64,12 +68,35 @@ def _tkey(*ts):
 class _FusedBlock(nn.Module):
     """Shared machinery: run ``conv -> LeakyReLU -> BatchNorm(eval) [-> + resid]`` as one launch."""
 
-    def _run(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], srcs, resid=None, act=True):
+    def _folded_bn(self, p: _Prepared, bn: Optional[nn.BatchNorm2d]):
+        if bn is None:
+            return None, None
+        bkey = _tkey(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        if p.bn_key != bkey:
+            p.bn_a, p.bn_b = ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+            p.bn_key = bkey
+        return p.bn_a, p.bn_b
+
+    def _run_h8(self, p: _Prepared, conv: nn.Conv2d, bn, srcs, resid, act, out_f32):
+        """Half-precision inference form: sources / residual / result are h8 tensors (see h8.py)."""
+        wkey = _tkey(conv.weight)
+        if p.key8 != wkey:
+            p.wpack8 = h8.pack_conv_weight_h8(conv.weight.detach().contiguous())
+            p.key8 = wkey
+        bn_a, bn_b = self._folded_bn(p, bn)
+        return h8.conv2d_h8([h8.H8Source(s.tensor, s.scale, s.nbatch) for s in srcs], p.wpack8, conv.in_channels,
+                            conv.out_channels, conv.kernel_size[0], conv.dilation[0], conv.padding[0],
+                            bias=None if conv.bias is None else conv.bias.detach(), slope=_SLOPE if act else None,
+                            bn_a=bn_a, bn_b=bn_b, resid=resid, out_f32_nchw=out_f32)
+
+    def _run(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], srcs, resid=None, act=True, out_f32=False):
         cache: Dict[str, _Prepared] = self.__dict__.setdefault("_prep", {})
         name = str(id(conv))
         p = cache.get(name)
         if p is None:
             p = cache[name] = _Prepared()
+        if srcs[0].tensor.dtype == torch.float16:
+            return self._run_h8(p, conv, bn, srcs, resid, act, out_f32)
         wkey = _tkey(conv.weight)
         if p.key != wkey:
             p.wpack = ops.pack_conv_weight(conv.weight.detach().contiguous())
@@ -85,13 +112,7 @@ class _FusedBlock(nn.Module):
                            [s.pixel_shuffle for s in srcs], bn, conv.out_channels, p.wpack, p.dgrad)
             return ConvLayerFn.apply(cfg, conv.weight, conv.bias, None if bn is None else bn.weight,
                                      None if bn is None else bn.bias, resid, *[s.tensor for s in srcs])
-        bn_a = bn_b = None
-        if bn is not None:
-            bkey = _tkey(bn.weight, bn.bias, bn.running_mean, bn.running_var)
-            if p.bn_key != bkey:
-                p.bn_a, p.bn_b = ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
-                p.bn_key = bkey
-            bn_a, bn_b = p.bn_a, p.bn_b
+        bn_a, bn_b = self._folded_bn(p, bn)
         wpack, precision = p.wpack, "fp32"
         if _CONV_PRECISION == "f16x3":
             precision = "f16x3"
@@ -168,8 +189,10 @@ class ResBlock(_FusedBlock):
         full = self.features(x)
         s = None
         if self.drop_out:
-            s = _draw(self.dropout, full.shape[0], full.shape[1], full.device, _scales, _name + ".dropout")
+            s = _draw(self.dropout, full.shape[0], self.conv5.out_channels, full.device, _scales, _name + ".dropout")
         if self.pooling:
+            if full.dtype == torch.float16:
+                return h8.avgpool3s2_h8(full, s), full
             pooled = AvgPoolFn.apply(full, s) if (torch.is_grad_enabled() and full.requires_grad) else ops.avgpool3s2(full, s)
             return pooled, full
         return full, s
@@ -195,8 +218,8 @@ class UpBlock(_FusedBlock):
         """x is read through PixelShuffle(2); x_scale is the producer's deferred dropout multiplier.
         skip_nbatch > 0: `skip` holds that many images shared by the stacked MC passes.
         Returns (out, deferred multiplier of dropout3 or None)."""
-        n, cx, dev = x.shape[0], x.shape[1], x.device
-        cu, cs = cx // 4, skip.shape[1]
+        n, cx, dev = x.shape[0], self.in_filters, x.device
+        cu, cs = cx // 4, self.conv1.in_channels - cx // 4
         sx, ss = x_scale, None
         if self.drop_out:
             d1 = _draw(self.dropout1, n, cu, dev, _scales, _name + ".dropout1")
@@ -207,15 +230,20 @@ class UpBlock(_FusedBlock):
                 ss = d2[:, cu:].contiguous()
             if up is not None:      # shuffled channel c is fed by stored channels 4c..4c+3
                 sx = _mul(sx, up.repeat_interleave(4, dim=1))
-        if sx is not None:
-            sx = sx.contiguous()
-        e1 = self._run(self.conv1, self.bn1, [ConvSource(x, sx, True), ConvSource(skip, ss, False, skip_nbatch)])
+        if x.dtype == torch.float16:
+            # h8: PixelShuffle is a (tiny) data-movement launch that also applies the producer's multiplier and dropout1/2
+            xs = h8.pixel_shuffle_h8(x, None if sx is None else sx.contiguous())
+            e1 = self._run(self.conv1, self.bn1, [ConvSource(xs), ConvSource(skip, ss, False, skip_nbatch)])
+        else:
+            if sx is not None:
+                sx = sx.contiguous()
+            e1 = self._run(self.conv1, self.bn1, [ConvSource(x, sx, True), ConvSource(skip, ss, False, skip_nbatch)])
         e2 = self._run(self.conv2, self.bn2, [ConvSource(e1)])
         e3 = self._run(self.conv3, self.bn3, [ConvSource(e2)])
         out = self._run(self.conv4, self.bn4, [ConvSource(e1), ConvSource(e2), ConvSource(e3)])
         s3 = None
         if self.drop_out:
-            s3 = _draw(self.dropout3, n, out.shape[1], dev, _scales, _name + ".dropout3")
+            s3 = _draw(self.dropout3, n, self.out_filters, dev, _scales, _name + ".dropout3")
         return out, s3
 
 
@@ -264,11 +292,15 @@ class SalsaNext(_FusedBlock):
         b = x.shape[0]
         n = int(T) * b
         x = x.contiguous().float()
+        half = _CONV_PRECISION == "f16"
+        if half:
+            x = h8.to_h8(x)
         d = self.downCntx3(self.downCntx2(self.downCntx(x)))
         d0c, d0b = self.resBlock1(d, scales, "resBlock1")               # no dropout in this block
         full2 = self.resBlock2.features(d0c)                             # deterministic; also the skip of upBlock3
-        s2 = _draw(self.resBlock2.dropout, n, full2.shape[1], x.device, scales, "resBlock2.dropout")
-        d1c = ops.avgpool3s2_bcast(full2, s2, n)                         # from here on: T*B stacked passes
+        s2 = _draw(self.resBlock2.dropout, n, self.resBlock2.conv5.out_channels, x.device, scales, "resBlock2.dropout")
+        # from here on: T*B stacked passes
+        d1c = h8.avgpool3s2_h8(full2, s2, n) if half else ops.avgpool3s2_bcast(full2, s2, n)
         d2c, d2b = self.resBlock3(d1c, scales, "resBlock3")
         d3c, d3b = self.resBlock4(d2c, scales, "resBlock4")
         d5c, s5 = self.resBlock5(d3c, scales, "resBlock5")
@@ -276,7 +308,13 @@ class SalsaNext(_FusedBlock):
         u3, s = self.upBlock2(u4, d2b, s, scales, "upBlock2")
         u2, s = self.upBlock3(u3, full2, s, scales, "upBlock3", skip_nbatch=b)
         u1, _ = self.upBlock4(u2, d0b, s, scales, "upBlock4", skip_nbatch=b)
-        return self._run(self.logits, None, [ConvSource(u1)], act=False)
+        return self._run(self.logits, None, [ConvSource(u1)], act=False, out_f32=True)
+
+    def _inference_only(self) -> bool:
+        """True when no autograd graph is wanted and every BatchNorm is frozen (the half-precision path has no backward)."""
+        if any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)):
+            return False
+        return not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
 
     def _forward(self, x, scales):
         if not isinstance(x, torch.Tensor) or x.dim() != 4:
@@ -287,6 +325,8 @@ class SalsaNext(_FusedBlock):
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise RuntimeError("SalsaNext needs H and W divisible by 16")
         x = x.contiguous().float()
+        if _CONV_PRECISION == "f16" and self._inference_only():
+            x = h8.to_h8(x)             # everything downstream stays in the fp16 channel-blocked layout
         d = self.downCntx(x)
         d = self.downCntx2(d)
         d = self.downCntx3(d)
@@ -299,4 +339,4 @@ class SalsaNext(_FusedBlock):
         u3, s = self.upBlock2(u4, d2b, s, scales, "upBlock2")
         u2, s = self.upBlock3(u3, d1b, s, scales, "upBlock3")
         u1, _ = self.upBlock4(u2, d0b, s, scales, "upBlock4")
-        return self._run(self.logits, None, [ConvSource(u1)], act=False)
+        return self._run(self.logits, None, [ConvSource(u1)], act=False, out_f32=True)
