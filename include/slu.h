@@ -267,7 +267,7 @@ typedef struct slu_conv_h8_desc {   /* HOST struct */
   const float* bn_b;
   const void* resid;     /* h8 [N][ceil(Cout/8)][H][W][8] or NULL                                                    */
   void* out;             /* h8 [N][ceil(Cout/8)][H][W][8], or fp32 [N][Cout][H][W] when out_f32_nchw                  */
-  int32_t out_f32_nchw;  /* 1: the logits head (SalsaNext.py:213) keeps the reference's fp32 NCHW output             */
+  int32_t out_f32_nchw;  /* 1: the logits head (SalsaNext.py:213) keeps the reference's fp32 NCHW output; 1x1 convs only */
 } slu_conv_h8_desc;
 
 size_t slu_packed_weight_bytes_h8(int cout, int cin, int ksize);

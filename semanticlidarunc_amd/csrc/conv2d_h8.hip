@@ -13,6 +13,7 @@
 //   conv1x1_h8_kernel   1x1 convs: no halo => B operands straight from global memory, weights through LDS
 //   plus layout / pooling / pixel-shuffle helpers at the end of the file.
 #include <stdio.h>
+#include <stdlib.h>
 #include "slu_common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -39,6 +40,7 @@ struct H8Args {
   float slope;
   int out_f32;         // 1: `out` is fp32 NCHW [N][Cout][H][W] (the logits head); 0: h8
   int tiles_x, tiles_y;
+  int dbg;             // development knobs (SLU_H8_DBG): 1 skip MFMAs, 2 skip re-staging, 4 skip the epilogue
 };
 
 struct SrcSel {
@@ -108,46 +110,89 @@ __device__ __forceinline__ void store_tile(const H8Args& a, const f32x16& acc, c
   }
 }
 
+// the source of every out-of-range / padding record of an LDS-DMA copy (never written)
+__device__ uint4 g_zero_rec;
+// where the lanes of a border tile that lie outside the image store (so that every lane of every tile issues its stores)
+__device__ uint4 g_trash_rec;
+
+// Epilogue of the persistent kernel (h8 output): EVERY lane issues its 4 stores (and its 4 residual loads when they were
+// not prefetched) -- lanes outside the image / past the last channel block read the zero record and store to a scratch
+// record -- so the number of vector-memory operations per tile is a compile-time constant the kernel's counted waits rely on.
+template <int STRIDE, bool PRE>
+__device__ __forceinline__ void store_tile_full(const H8Args& a, const f32x16& acc, const float* se, int cl0, int go0, int hh, bool pix_ok, size_t n,
+                                                size_t pix, size_t HW, const uint2* __restrict__ resid, const uint2 (&rv)[4],
+                                                uint2* __restrict__ out, float slope_pre) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cl = cl0 + 8 * q + 4 * hh + k;
+      float t = acc[4 * q + k] + se[cl];
+      t = t > 0.0f ? t : t * slope_pre;
+      v[k] = t * se[STRIDE + cl] + se[2 * STRIDE + cl];
+    }
+    const bool ok = pix_ok && go0 + q < a.Gout;
+    const size_t idx = ((n * a.Gout + go0 + q) * HW + pix) * 2 + hh;
+    if (resid) {
+      const uint2 r = PRE ? rv[q] : *(ok ? resid + idx : reinterpret_cast<const uint2*>(&g_zero_rec));
+      const half2v r0 = __builtin_bit_cast(half2v, r.x), r1 = __builtin_bit_cast(half2v, r.y);
+      v[0] += (float)r0[0]; v[1] += (float)r0[1]; v[2] += (float)r1[0]; v[3] += (float)r1[1];
+    }
+    *(ok ? out + idx : reinterpret_cast<uint2*>(&g_trash_rec)) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+  }
+}
+
+
+// one global_load_lds_dwordx4: lane l copies the 16 bytes at its own `gsrc` to LDS address `ldst_wave_base + 16 l`
+#define SLU_GLDS16(gsrc, ldst_wave_base)                                                                  \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),                 \
+                                   (__attribute__((address_space(3))) void*)(ldst_wave_base), 16, 0, 0)
+
 // -----------------------------------------------------------------------------------------------------------
-// Tiled kernel.  Workgroup = WM x WN waves; output tile = TH rows x 64 columns x (32 WM MB) channels.
-// Per chunk of KC K-steps (16 KC channels): stage the input tile (2 KC blocks, halo included) and the weight
-// fragments into LDS, then T * KC MFMA steps.  SCALED: per-(image, channel) multipliers applied while staging
-// (Dropout2d on a concatenated input).
+// Tiled kernel, persistent, LDS-DMA staged.  Workgroup = WM x WN waves; output tile = TH rows x 64 columns x
+// (32 WM MB) channels.  A workgroup walks a contiguous run of tiles (consecutive along the azimuth, so neighbouring
+// halos hit L2).  The unit of staging is a chunk = one K-step (16 channels): the input tile (2 channel blocks,
+// halo included) and the weight fragments are copied global -> LDS by global_load_lds (no staging registers),
+// into the buffer the previous chunk is not using, while the T MFMA steps of the current chunk run; the chunk
+// after a tile's last one is the first chunk of the NEXT tile, so loads stay in flight across the epilogue.
+// One barrier per chunk.  WRES: the weight fragments of ALL K-steps stay in LDS for the whole kernel (small
+// layers).  SCALED: per-(image, channel) multipliers (Dropout2d on a concatenated input) are applied to the B
+// fragments after the LDS read.
 // -----------------------------------------------------------------------------------------------------------
-template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, int KC, bool SCALED>
-__global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : 3) void conv_h8_kernel(const H8Args a, const void* __restrict__ resid,
-                                                                                       void* __restrict__ out) {
-  constexpr int NT = 64 * WM * WN;
+template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool SCALED, bool WRES, bool F32OUT>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 || MB >= 2 || RPW >= 2) ? 2 : 3) void conv_h8_kernel(const H8Args a, const void* __restrict__ resid,
+                                                                                                       void* __restrict__ out) {
+  constexpr int NWAVE = WM * WN;
   constexpr int T = KS * KS;
   constexpr int TW = 64, TH = WN * RPW, NB = 2 * RPW;
   constexpr int LW = TW + 2 * PAD, LH = TH + 2 * PAD;
   constexpr int REC = LH * LW;                      // records per channel block
-  constexpr int GPC = 2 * KC;                       // channel blocks per chunk
   constexpr int MBLK = WM * MB;
-  constexpr int NITEM = GPC * REC, NI = (NITEM + NT - 1) / NT;
-  constexpr int NWV = MBLK * KC * T * 64, NW = (NWV + NT - 1) / NT;
+  constexpr int NREC_B = 2 * REC, NBLK_B = (NREC_B + 63) / 64;          // 64-record pieces of the input tile of a chunk
+  constexpr int NB_ALLOC = NBLK_B * 64;
+  constexpr int NREC_A = MBLK * T * 64, NBLK_A = MBLK * T;              // weight fragments of a chunk
+  constexpr int NIB = (NBLK_B + NWAVE - 1) / NWAVE, NIA = (NBLK_A + NWAVE - 1) / NWAVE;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4* s_b = reinterpret_cast<uint4*>(smem);      // [GPC][LH][LW]
-  uint4* s_a = s_b + GPC * REC;                     // [MBLK][KC][T][64]
-  float* s_epi = reinterpret_cast<float*>(s_a + MBLK * KC * T * 64);
+  float* s_epi = reinterpret_cast<float*>(smem);                        // bias | bn_a | bn_b
+  uint4* s_scale = reinterpret_cast<uint4*>(s_epi + 3 * MBLK * 32);     // [2][64] fp16 multipliers per channel block (SCALED)
+  uint4* s_b = s_scale + (SCALED ? 128 : 0);                            // [2][NB_ALLOC]
+  uint4* s_a = s_b + 2 * NB_ALLOC;                                      // WRES: [MBLK][nks][T][64]; else [2][MBLK][T][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  int t = blockIdx.x;
-  {
-    const int nwg = gridDim.x, xcd = t & 7, qq = nwg >> 3, rr = nwg & 7;
-    t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (t >> 3);
-  }
-  const int tx = t % a.tiles_x;
-  t /= a.tiles_x;
-  const int ty = t % a.tiles_y;
-  const int n = t / a.tiles_y;
-  const int x0 = tx * TW, y0 = ty * TH;
   const int mblk0 = blockIdx.y * MBLK;
-  int img[SLU_MAX_SRC];
-#pragma unroll
-  for (int s = 0; s < SLU_MAX_SRC; ++s) img[s] = (s < a.nsrc && a.src[s].nb) ? n % a.src[s].nb : n;
+  // contiguous run of tiles of this workgroup; workgroups that share an XCD (blockIdx.x % 8) get neighbouring runs
+  int t_beg, t_end;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
+    t_beg = (int)(nt * w / nwg);
+    t_end = (int)(nt * (w + 1) / nwg);
+  }
+  if (t_beg >= t_end) return;
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -166,92 +211,195 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : 3) void conv_h8
   }
 
   const int hh = lane >> 5, jj = lane & 31;
-  const int bbase = hh * REC + (wn * RPW) * LW + jj;          // + ks*2*REC + (rr + dy)*LW + cb*32 + dx
-  const int abase = (wm * MB) * KC * T * 64 + lane;
   const size_t HW = (size_t)a.H * a.W;
+  const float slope_pre = (a.has_act & 3) == 1 ? a.slope : 1.0f;
+  const int nks = a.nks;
+  const int a_stride = WRES ? nks * T * 64 : T * 64;                    // uint4 per channel block in s_a
+  const int abase = (wm * MB) * a_stride + lane;
+  const int bbase = hh * REC + (wn * RPW) * LW + jj;                    // + (rr + dy)*LW + cb*32 + dx
 
-  uint4 st[NI];
-  auto fetch_tile = [&](int q, int tq) {
+  struct TilePos { int x0, y0, n; };
+  auto decode = [&](int t) {
+    TilePos p;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    p.x0 = tx * TW;
+    p.y0 = (t % a.tiles_y) * TH;
+    p.n = t / a.tiles_y;
+    return p;
+  };
+  // Per-lane description of the input-tile pieces this wave copies (the same for every chunk and tile): piece i covers
+  // records [64 (i NWAVE + wave), +64) of the [2][LH][LW] tile image; pc_rc = row | col << 8 | block << 16 | inside << 17.
+  int pc_rc[NIB], pc_off[NIB];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int e = tq + i * NT;
-      const int g2 = e / REC;
-      const int rem = e - g2 * REC;
-      const int r = rem / LW;
-      const int c = rem - r * LW;
-      const int gy = y0 + r - PAD, gx = x0 + c - PAD;
-      const int g = q * GPC + g2;
-      const bool ok = (NITEM % NT == 0 || e < NITEM) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && g < a.Gin;
-      const SrcSel p = select_src(a, img, ok ? g : 0);
-      const size_t idx = ok ? ((size_t)p.ns * p.G + p.gl) * HW + (size_t)gy * a.W + gx : 0;
-      uint4 v = p.ptr[idx];
-      if constexpr (SCALED) {
-        if (ok && p.scale) v = scale_record(v, p.scale + ((size_t)n * p.G + p.gl) * 8);
+  for (int i = 0; i < NIB; ++i) {
+    const int e = (i * NWAVE + wave) * 64 + lane;
+    const int g2 = e / REC;
+    const int rem = e - g2 * REC;
+    const int r = rem / LW;
+    const int c = rem - r * LW;
+    pc_rc[i] = r | (c << 8) | ((g2 & 1) << 16) | ((e < NREC_B ? 1 : 0) << 17);
+    pc_off[i] = r * a.W + c;
+  }
+  // LDS-DMA of chunk q of tile tp into input buffer `buf` (and, unless WRES, its weight fragments into weight buffer `buf`)
+  auto stage = [&](const TilePos& tp, int q, int buf) {
+    int img[SLU_MAX_SRC];
+#pragma unroll
+    for (int s = 0; s < SLU_MAX_SRC; ++s) img[s] = (s < a.nsrc && a.src[s].nb) ? tp.n % a.src[s].nb : tp.n;
+    // wave-uniform: the two channel blocks of this K-step, as byte addresses of the record at tile-image position (0, 0)
+    uintptr_t base[2];
+    bool live[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int g = 2 * q + h;
+      live[h] = g < a.Gin;
+      const SrcSel p = select_src(a, img, live[h] ? g : 0);
+      base[h] = reinterpret_cast<uintptr_t>(p.ptr) +
+                16 * ((long long)(((size_t)p.ns * p.G + p.gl) * HW) + (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD));
+    }
+    const uintptr_t zero = reinterpret_cast<uintptr_t>(&g_zero_rec);
+    uint4* db = s_b + buf * NB_ALLOC;
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int blk = i * NWAVE + wave;
+      if (NBLK_B % NWAVE == 0 || blk < NBLK_B) {
+        const int rc = pc_rc[i];
+        const int gy = tp.y0 - PAD + (rc & 255), gx = tp.x0 - PAD + ((rc >> 8) & 255);
+        const bool h1 = (rc >> 16) & 1;
+        const bool ok = (rc >> 17) && (h1 ? live[1] : live[0]) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const uintptr_t src = ok ? (h1 ? base[1] : base[0]) + 16 * (long long)pc_off[i] : zero;
+        SLU_GLDS16(reinterpret_cast<const uint4*>(src), db + blk * 64);
       }
-      st[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+    if constexpr (!WRES) {
+      uint4* da = s_a + buf * NREC_A;
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) {
+        const int blk = i * NWAVE + wave;                               // = m * T + tap
+        if (NBLK_A % NWAVE == 0 || blk < NBLK_A) {
+          const int m = blk / T;
+          const uint4* src = mblk0 + m < a.nmblk ? a.wpack + (((size_t)(mblk0 + m) * nks + q) * T + (blk - m * T)) * 64 + lane : &g_zero_rec;
+          SLU_GLDS16(src, da + blk * 64);
+        }
+      }
     }
   };
-  fetch_tile(0, tid);
+  // per-channel multipliers of image n as fp16, one record per channel block (SCALED)
+  auto stage_scales = [&](int n, int par) {
+    if (tid < 64) {
+      half8 h;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) h[k] = (_Float16)1.0f;
+      if (tid < a.Gin) {
+        int img[SLU_MAX_SRC] = {0, 0, 0};
+        const SrcSel p = select_src(a, img, tid);
+        if (p.scale) {
+          const float* sp = p.scale + ((size_t)n * p.G + p.gl) * 8;
+          const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+          h[0] = (_Float16)s0.x; h[1] = (_Float16)s0.y; h[2] = (_Float16)s0.z; h[3] = (_Float16)s0.w;
+          h[4] = (_Float16)s1.x; h[5] = (_Float16)s1.y; h[6] = (_Float16)s1.z; h[7] = (_Float16)s1.w;
+        }
+      }
+      s_scale[par * 64 + tid] = __builtin_bit_cast(uint4, h);
+    }
+  };
 
-  const int nq = (a.nks + KC - 1) / KC;
-  for (int q = 0; q < nq; ++q) {
-    __syncthreads();
-    int tq = tid;
-    asm volatile("" : "+v"(tq));
-    // ---- weight fragments of this chunk: [mblk][kstep][tap][lane] ----
-    uint4 sw[NW];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int e = tq + i * NT;
-      const int m = e / (KC * T * 64);
-      const int r = e - m * (KC * T * 64);
-      const int ks = r / (T * 64);
-      const bool ok = (NWV % NT == 0 || e < NWV) && mblk0 + m < a.nmblk && q * KC + ks < a.nks;
-      const size_t off = ok ? ((size_t)(mblk0 + m) * a.nks + q * KC) * (T * 64) + r : 0;
-      sw[i] = a.wpack[off];
-      if (!ok) sw[i] = make_uint4(0u, 0u, 0u, 0u);
+  if constexpr (WRES) {      // all weight fragments of this channel-block group, once
+    const int per_m = nks * T;
+    for (int blk = wave; blk < MBLK * per_m; blk += NWAVE) {
+      const int m = blk / per_m;
+      const uint4* src = mblk0 + m < a.nmblk ? a.wpack + ((size_t)(mblk0 + m) * per_m + (blk - m * per_m)) * 64 + lane : &g_zero_rec;
+      SLU_GLDS16(src, s_a + blk * 64);
     }
+  }
+  TilePos cur = decode(t_beg), nxt = cur;
+  stage(cur, 0, 0);
+  int buf = 0;
+  constexpr int NST = MB * NB * 4;                   // stores of a tile's epilogue, per wave (h8 output: every lane stores)
+  constexpr bool PRE = MB == 1 && !F32OUT;           // residual of the tile prefetched before its last MFMA phase
+  const uint2* resid2 = reinterpret_cast<const uint2*>(resid);
+  uint2 rv[PRE ? NB : 1][4];
+
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    const int spar = (tile - t_beg) & 1;
+    if constexpr (SCALED) stage_scales(cur.n, spar);
+    for (int q = 0; q < nks; ++q) {
+      // Chunk (tile, q) has landed and nobody reads the other buffer any more.  vmcnt counts loads, LDS-DMA and stores in
+      // issue order: at a tile's first chunk the only operations younger than the DMA we wait for are the NST stores of the
+      // previous tile's epilogue, which may stay in flight (waiting for them would expose the HBM write latency per tile).
+      if (!F32OUT && q == 0 && tile != t_beg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (q + 1 < nks) {
+        if (!(a.dbg & 2)) stage(cur, q + 1, buf ^ 1);
+      } else if (tile + 1 < t_end) {
+        nxt = decode(tile + 1);
+        if (!(a.dbg & 2)) stage(nxt, 0, buf ^ 1);
+      }
+      if constexpr (PRE) {
+        if (resid && q == nks - 1) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int e = tq + i * NT;
-      if (NITEM % NT == 0 || e < NITEM) s_b[e] = st[i];
-    }
+          for (int b = 0; b < NB; ++b) {
+            const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
+            const bool pix_ok = gy < a.H && gx < a.W;
+            const size_t pix = (size_t)gy * a.W + gx;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int e = tq + i * NT;
-      if (NWV % NT == 0 || e < NWV) s_a[e] = sw[i];
-    }
-    __syncthreads();
-    if (q + 1 < nq) fetch_tile(q + 1, tq);           // in flight during the MFMA phase below
-#pragma unroll
-    for (int ks = 0; ks < KC; ++ks) {
+            for (int k = 0; k < 4; ++k) {
+              const int go = (mblk0 + wm) * 4 + k;
+              rv[b][k] = *((pix_ok && go < a.Gout) ? resid2 + (((size_t)cur.n * a.Gout + go) * HW + pix) * 2 + hh
+                                                   : reinterpret_cast<const uint2*>(&g_zero_rec));
+            }
+          }
+        }
+      }
+      const uint4* sb = s_b + buf * NB_ALLOC + bbase;
+      const uint4* sa = s_a + abase + (WRES ? q * T * 64 : buf * NREC_A);
+      half8 sc;
+      if constexpr (SCALED) sc = __builtin_bit_cast(half8, s_scale[spar * 64 + 2 * q + hh]);
+      if (!(a.dbg & 1))
 #pragma unroll
       for (int tap = 0; tap < T; ++tap) {
         const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
         half8 af[MB];
 #pragma unroll
-        for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, s_a[abase + ((i * KC + ks) * T + tap) * 64]);
+        for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, sa[i * a_stride + tap * 64]);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          const half8 bf = __builtin_bit_cast(half8, s_b[bbase + ks * 2 * REC + ((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+          half8 bf = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+          if constexpr (SCALED) bf *= sc;
 #pragma unroll
           for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acc[i][b], 0, 0, 0);
         }
       }
+      buf ^= 1;
     }
-  }
-
-  const float slope_pre = (a.has_act & 3) == 1 ? a.slope : 1.0f;
+    if (!(a.dbg & 4)) {
 #pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    const int ml = wm * MB + i;
+      for (int i = 0; i < MB; ++i) {
+        const int ml = wm * MB + i;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int gy = y0 + wn * RPW + (b >> 1), gx = x0 + (b & 1) * 32 + jj;
-      const bool pix_ok = gy < a.H && gx < a.W;
-      store_tile<MBLK * 32>(a, acc[i][b], s_epi, ml * 32, (mblk0 + ml) * 32, hh, pix_ok, (size_t)n, pix_ok ? (size_t)gy * a.W + gx : 0, HW,
-                            resid, out, slope_pre);
+        for (int b = 0; b < NB; ++b) {
+          const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
+          const bool pix_ok = gy < a.H && gx < a.W;
+          const size_t pix = pix_ok ? (size_t)gy * a.W + gx : 0;
+          if constexpr (F32OUT)
+            store_tile<MBLK * 32>(a, acc[i][b], s_epi, ml * 32, (mblk0 + ml) * 32, hh, pix_ok, (size_t)cur.n, pix, HW, resid, out, slope_pre);
+          else
+            store_tile_full<MBLK * 32, PRE>(a, acc[i][b], s_epi, ml * 32, (mblk0 + ml) * 4, hh, pix_ok, (size_t)cur.n, pix, HW, resid2,
+                                            rv[PRE ? b : 0], reinterpret_cast<uint2*>(out), slope_pre);
+          __builtin_amdgcn_sched_barrier(0);     // one accumulator tile at a time (register pressure)
+        }
+      }
     }
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
+    cur = nxt;
   }
 }
 
@@ -519,59 +667,94 @@ int fill_h8(const slu_conv_h8_desc* d, H8Args& a) {
   a.has_act = d->has_act; a.slope = d->slope;
   a.out_f32 = d->out_f32_nchw ? 1 : 0;
   a.tiles_x = a.tiles_y = 0;
+  const char* dbg = getenv("SLU_H8_DBG");
+  a.dbg = dbg ? atoi(dbg) : 0;
   return SLU_OK;
 }
 
-template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, int KC, bool SCALED>
-int launch_h8(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
-  constexpr int TH = WN * RPW, MBLK = WM * MB, T = KS * KS;
-  constexpr size_t lds = (size_t)2 * KC * (TH + 2 * PAD) * (64 + 2 * PAD) * 16 + (size_t)MBLK * KC * T * 64 * 16 + (size_t)3 * MBLK * 32 * 4;
-  static_assert(lds <= 160 * 1024, "LDS budget");
+template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool SCALED, bool WRES, bool F32OUT = false>
+int launch_h8_k(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
+  constexpr int TH = WN * RPW, MBLK = WM * MB, T = KS * KS, NWAVE = WM * WN;
+  constexpr int WAVES_PER_SIMD = (NWAVE >= 8 || MB >= 2 || RPW >= 2) ? 2 : 3;       // the kernel's __launch_bounds__
+  constexpr size_t nb_alloc = (size_t)((2 * (TH + 2 * PAD) * (64 + 2 * PAD) + 63) / 64) * 64;
+  const size_t lds = (size_t)3 * MBLK * 32 * 4 + (SCALED ? 2048 : 0) + 2 * nb_alloc * 16 + (size_t)MBLK * (WRES ? a.nks : 2) * T * 64 * 16;
+  if (lds > 160 * 1024) return SLU_EUNSUPPORTED;
+  if (SCALED && a.Gin > 64) return SLU_EUNSUPPORTED;
   a.tiles_x = (a.W + 63) / 64;
   a.tiles_y = (a.H + TH - 1) / TH;
-  const long long gx = (long long)a.tiles_x * a.tiles_y * a.N;
+  const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
   const int gy = (a.nmblk + MBLK - 1) / MBLK;
-  if (gx <= 0 || gx > 0x7fffffffLL || gy > 65535) return SLU_EUNSUPPORTED;
-  auto kern = conv_h8_kernel<KS, DIL, PAD, MB, WM, WN, RPW, KC, SCALED>;
-  static bool attr_set = false;     // benign race: the call is idempotent
-  if (!attr_set) {
+  if (nt <= 0 || nt > 0x7fffffffLL || gy > 65535) return SLU_EUNSUPPORTED;
+  // persistent grid: as many workgroups as fit on the 256 CUs at once (registers / LDS), never more than tiles
+  long long per_cu = WAVES_PER_SIMD * 4 / NWAVE;
+  const long long by_lds = (long long)(160 * 1024 / lds);
+  if (by_lds < per_cu) per_cu = by_lds;
+  if (per_cu < 1) per_cu = 1;
+  long long gx = (256 * per_cu + gy - 1) / gy;
+  if (const char* f = getenv("SLU_H8_GRIDMUL")) gx = gx * atoi(f);
+  if (gx < 8) gx = 8;
+  if (gx > nt) gx = nt;
+  auto kern = conv_h8_kernel<KS, DIL, PAD, MB, WM, WN, RPW, SCALED, WRES, F32OUT>;
+  static size_t attr_lds = 0;       // benign race: the call is idempotent
+  if (lds > attr_lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SLU_ELAUNCH;
-    attr_set = true;
+    attr_lds = lds;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64 * WM * WN), lds, st, a, d->resid, d->out);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64 * NWAVE), lds, st, a, d->resid, d->out);
   SLU_CHECK_LAUNCH();
+}
+
+constexpr size_t WRES_MAX_BYTES = 24 * 1024;
+
+// weights of all K-steps stay resident in LDS when they are small (full-resolution 32-channel layers)
+template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool SCALED>
+int launch_h8(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
+  const size_t wbytes = (size_t)WM * MB * a.nks * KS * KS * 64 * 16;
+  if (wbytes <= WRES_MAX_BYTES) return launch_h8_k<KS, DIL, PAD, MB, WM, WN, RPW, SCALED, true>(a, d, st);
+  return launch_h8_k<KS, DIL, PAD, MB, WM, WN, RPW, SCALED, false>(a, d, st);
 }
 
 inline long long wg_count(const H8Args& a, int th, int mblk) {
   return (long long)a.N * ((a.H + th - 1) / th) * ((a.W + 63) / 64) * ((a.nmblk + mblk - 1) / mblk);
 }
 
-// 0: 32 ch x 8 rows, 1: 64 ch x 8 rows, 2: 128 ch x 4 rows, 3: 32 ch x 4 rows, 4: 64 ch x 4 rows
+// tile configurations {MB, WM, WN, RPW}: 8-wave workgroups (16 or 8 rows) when the layer has enough tiles for
+// every CU, 4-wave ones with 8 / 4 rows for the small feature maps at the bottom of the U-Net
+enum { CFG_M32_TH16 = 0, CFG_M64_TH16, CFG_M128_TH8, CFG_M32_TH8, CFG_M64_TH8, CFG_M128_TH4, CFG_M32_TH4, CFG_M64_TH4, CFG_COUNT };
+const int CFG_TABLE[CFG_COUNT][4] = {{1, 1, 8, 2}, {2, 1, 8, 2}, {2, 2, 4, 2}, {1, 1, 4, 2}, {2, 1, 4, 2}, {2, 2, 2, 2}, {1, 1, 4, 1}, {2, 1, 4, 1}};
+
 int choose_h8(const H8Args& a) {
-  const long long want = 512;
+  if (const char* f = getenv("SLU_H8_CFG")) return atoi(f);
+  const long long want = 256;
   if (a.nmblk >= 4) {
-    if (wg_count(a, 4, 4) >= want) return 2;
-    if (wg_count(a, 4, 2) >= want) return 4;
-    return 3;
+    if (a.H >= 8 && wg_count(a, 8, 4) >= want) return CFG_M128_TH8;
+    if (wg_count(a, 4, 4) >= want) return CFG_M128_TH4;
+    if (wg_count(a, 4, 2) >= want) return CFG_M64_TH4;
+    return CFG_M32_TH4;
   }
   if (a.nmblk >= 2) {
-    if (a.H >= 8 && wg_count(a, 8, 2) >= want) return 1;
-    if (wg_count(a, 4, 2) >= want) return 4;
-    return 3;
+    if (a.H >= 16 && wg_count(a, 16, 2) >= want) return CFG_M64_TH16;
+    if (a.H >= 8 && wg_count(a, 8, 2) >= want) return CFG_M64_TH8;
+    if (wg_count(a, 4, 2) >= want) return CFG_M64_TH4;
+    return CFG_M32_TH4;
   }
-  if (a.H >= 8 && wg_count(a, 8, 1) >= want) return 0;
-  return 3;
+  if (a.H >= 16 && wg_count(a, 16, 1) >= want) return CFG_M32_TH16;
+  if (a.H >= 8 && wg_count(a, 8, 1) >= want) return CFG_M32_TH8;
+  return CFG_M32_TH4;
 }
 
 template <int KS, int DIL, int PAD, bool SCALED>
 int launch_h8_tiles(H8Args& a, const slu_conv_h8_desc* d, int cfg, hipStream_t st) {
   switch (cfg) {
-    case 0: return launch_h8<KS, DIL, PAD, 1, 1, 4, 2, 1, SCALED>(a, d, st);
-    case 1: return launch_h8<KS, DIL, PAD, 2, 1, 4, 2, 1, SCALED>(a, d, st);
-    case 2: return launch_h8<KS, DIL, PAD, 2, 2, 2, 2, 1, SCALED>(a, d, st);
-    case 3: return launch_h8<KS, DIL, PAD, 1, 1, 4, 1, 1, SCALED>(a, d, st);
-    case 4: return launch_h8<KS, DIL, PAD, 2, 1, 4, 1, 1, SCALED>(a, d, st);
+    case CFG_M32_TH16: return launch_h8<KS, DIL, PAD, 1, 1, 8, 2, SCALED>(a, d, st);
+    case CFG_M64_TH16: return launch_h8<KS, DIL, PAD, 2, 1, 8, 2, SCALED>(a, d, st);
+    case CFG_M128_TH8: return launch_h8<KS, DIL, PAD, 2, 2, 4, 2, SCALED>(a, d, st);
+    case CFG_M32_TH8:  return launch_h8<KS, DIL, PAD, 1, 1, 4, 2, SCALED>(a, d, st);
+    case CFG_M64_TH8:  return launch_h8<KS, DIL, PAD, 2, 1, 4, 2, SCALED>(a, d, st);
+    case CFG_M128_TH4: return launch_h8<KS, DIL, PAD, 2, 2, 2, 2, SCALED>(a, d, st);
+    case CFG_M32_TH4:  return launch_h8<KS, DIL, PAD, 1, 1, 4, 1, SCALED>(a, d, st);
+    case CFG_M64_TH4:  return launch_h8<KS, DIL, PAD, 2, 1, 4, 1, SCALED>(a, d, st);
   }
   return SLU_EUNSUPPORTED;
 }
@@ -630,8 +813,12 @@ extern "C" int slu_conv2d_h8_fwd(const slu_conv_h8_desc* d, slu_stream_t stream)
     if (a.nmblk <= 4) return launch_h8_1x1<4, 1>(a, d, st);
     return launch_h8_1x1<8, 1>(a, d, st);
   }
-  const int cfg = choose_h8(a);
   const bool sc = any_scale(d);
+  if (a.out_f32) {      // fp32 NCHW output outside the streaming kernel's reach (odd H*W): 1x1 head only
+    if (d->ksize != 1 || d->dil != 1 || d->pad != 0 || sc) return SLU_EUNSUPPORTED;
+    return launch_h8_k<1, 1, 0, 1, 1, 4, 1, false, false, true>(a, d, st);
+  }
+  const int cfg = choose_h8(a);
   if (d->ksize == 1 && d->dil == 1 && d->pad == 0) return launch_h8_family<1, 1, 0>(a, d, cfg, sc, st);
   if (d->ksize == 3 && d->dil == 1 && d->pad == 1) return launch_h8_family<3, 1, 1>(a, d, cfg, sc, st);
   if (d->ksize == 3 && d->dil == 2 && d->pad == 2) return launch_h8_family<3, 2, 2>(a, d, cfg, sc, st);
@@ -649,10 +836,14 @@ extern "C" int slu_conv2d_h8_kernel_name(const slu_conv_h8_desc* d, char* buf, s
     snprintf(buf, n, "conv1x1_h8_kernel<%d, %d>", mb, mb <= 2 ? 2 : 1);
     return SLU_OK;
   }
-  static const int cfgs[5][4] = {{1, 1, 4, 2}, {2, 1, 4, 2}, {2, 2, 2, 2}, {1, 1, 4, 1}, {2, 1, 4, 1}};
-  const int* c = cfgs[choose_h8(a)];
-  snprintf(buf, n, "conv_h8_kernel<%d, %d, %d, %d, %d, %d, %d, 1, %s>", d->ksize, d->dil, d->pad, c[0], c[1], c[2], c[3],
-           any_scale(d) ? "true" : "false");
+  if (a.out_f32) {
+    snprintf(buf, n, "conv_h8_kernel<1, 1, 0, 1, 1, 4, 1, false, false, true>");
+    return SLU_OK;
+  }
+  const int* c = CFG_TABLE[choose_h8(a)];
+  const bool wres = (size_t)c[0] * c[1] * a.nks * d->ksize * d->ksize * 64 * 16 <= WRES_MAX_BYTES;
+  snprintf(buf, n, "conv_h8_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %s, false>", d->ksize, d->dil, d->pad, c[0], c[1], c[2], c[3],
+           any_scale(d) ? "true" : "false", wres ? "true" : "false");
   return SLU_OK;
 }
 

@@ -113,7 +113,7 @@ def test_concat_scales_broadcast_and_fp32_head(cuda):
     _conv_case(cuda, 4, [32, 32], 32, 16, 64, (1, 1, 0), seed=14, nbatch_last=1)           # streaming kernel + broadcast
     _conv_case(cuda, 2, [32], 20, 64, 512, (1, 1, 0), seed=15, out_f32=True)               # logits head
     _conv_case(cuda, 2, [5], 32, 64, 512, (1, 1, 0), seed=16, resid=False)                 # first layer (5 real channels)
-    _conv_case(cuda, 1, [32], 20, 5, 33, (3, 1, 1), seed=17, out_f32=True)
+    _conv_case(cuda, 1, [32], 20, 5, 33, (1, 1, 0), seed=17, out_f32=True)                # odd H*W: tiled form of the head
 
 
 def test_conv_argument_checks(cuda):
