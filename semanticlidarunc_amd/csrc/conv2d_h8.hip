@@ -372,6 +372,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 || MB >= 2 || RPW >= 2)
 #pragma unroll
           for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acc[i][b], 0, 0, 0);
         }
+        // ask for an MFMA / LDS-read interleave: each tap's fragment reads are spread between the previous tap's MFMAs
+#pragma unroll
+        for (int k = 0; k < MB * NB; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, (MB + NB + MB * NB - 1) / (MB * NB), 0);
+        }
       }
       buf ^= 1;
     }
@@ -505,6 +511,107 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
 #pragma unroll
     for (int b = 0; b < NBW; ++b)
       store_tile<MB * 32>(a, acc[i][b], s_epi, i * 32, i * 32, hh, live[b], (size_t)nimg[b], (size_t)hw[b], (size_t)HW, resid, out, slope_pre);
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// 1x1 convs with few output channels (MB <= 2 blocks of 32) and few input channels (NKS K-steps, all of them resident
+// in LDS as weight fragments): pure streaming.  No barrier after the prologue: a wave takes one block of 32 pixels at
+// a time (grid-stride, so the chip sweeps memory as one front), issues ALL its NKS input loads (16 B per lane each, two
+// 512-byte runs per wave) and the residual loads at once, and multiplies as they arrive.  Memory-level parallelism
+// comes from occupancy (4-5 waves per SIMD, up to NKS KB in flight per wave); LDS only serves the A fragments.
+// -----------------------------------------------------------------------------------------------------------
+template <int MB, int NKS>
+__global__ __launch_bounds__(256, (MB * NKS >= 12) ? 2 : ((MB * NKS >= 2) ? 3 : 4)) void conv1x1_h8_res_kernel(const H8Args a, const void* __restrict__ resid, void* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_epi = reinterpret_cast<float*>(smem);                 // bias | bn_a | bn_b
+  uint4* s_a = reinterpret_cast<uint4*>(s_epi + 3 * MB * 32);    // [MB][NKS][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, jj = lane & 31;
+  const long long HW = (long long)a.H * a.W;
+  const long long nblocks = (long long)a.N * HW / 32;
+
+  if (tid < MB * 32) {
+    const bool ok = tid < a.Cout;
+    s_epi[tid] = (ok && a.bias) ? a.bias[tid] : 0.0f;
+    s_epi[MB * 32 + tid] = (ok && a.bn_a) ? a.bn_a[tid] : 1.0f;
+    s_epi[2 * MB * 32 + tid] = (ok && a.bn_a) ? a.bn_b[tid] : 0.0f;
+  }
+  for (int e = tid; e < MB * NKS * 64; e += 256) {
+    const int m = e / (NKS * 64);
+    const int r = e - m * (NKS * 64);
+    const bool ok = m < a.nmblk && (r >> 6) < a.nks;
+    s_a[e] = ok ? a.wpack[(size_t)m * a.nks * 64 + r] : make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+
+  const float slope_pre = (a.has_act & 3) == 1 ? a.slope : 1.0f;
+  const uint2* resid2 = reinterpret_cast<const uint2*>(resid);
+  const long long stride = (long long)gridDim.x * 4;
+  for (long long pb = (long long)blockIdx.x * 4 + wave; pb < nblocks; pb += stride) {
+    const long long pix = pb * 32 + jj;
+    const int n = (int)(pix / HW);
+    const size_t hw = (size_t)(pix - n * HW);
+    int img[SLU_MAX_SRC];
+#pragma unroll
+    for (int s = 0; s < SLU_MAX_SRC; ++s) img[s] = (s < a.nsrc && a.src[s].nb) ? n % a.src[s].nb : n;
+    uint4 x[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int g = 2 * ks + hh;                        // this lane half's channel block
+      const bool ok = g < a.Gin;
+      const SrcSel p = select_src(a, img, ok ? g : 0);
+      const uint4 v = p.ptr[ok ? ((size_t)p.ns * p.G + p.gl) * HW + hw : 0];
+      x[ks] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint2 rv[MB][4];
+    if (resid) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int go = i * 4 + q;
+          rv[i][q] = go < a.Gout ? resid2[(((size_t)n * a.Gout + go) * HW + hw) * 2 + hh] : make_uint2(0u, 0u);
+        }
+    }
+    f32x16 acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, s_a[(i * NKS + ks) * 64 + lane]), __builtin_bit_cast(half8, x[ks]),
+                                                        acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      if (a.out_f32) {
+        store_tile<MB * 32>(a, acc[i], s_epi, i * 32, i * 32, hh, true, (size_t)n, hw, (size_t)HW, nullptr, out, slope_pre);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int cl = i * 32 + 8 * q + 4 * hh + k;
+            float t = acc[i][4 * q + k] + s_epi[cl];
+            t = t > 0.0f ? t : t * slope_pre;
+            v[k] = t * s_epi[MB * 32 + cl] + s_epi[2 * MB * 32 + cl];
+          }
+          if (resid) {
+            const half2v r0 = __builtin_bit_cast(half2v, rv[i][q].x), r1 = __builtin_bit_cast(half2v, rv[i][q].y);
+            v[0] += (float)r0[0]; v[1] += (float)r0[1]; v[2] += (float)r1[0]; v[3] += (float)r1[1];
+          }
+          const int go = i * 4 + q;
+          if (go < a.Gout)
+            reinterpret_cast<uint2*>(out)[(((size_t)n * a.Gout + go) * HW + hw) * 2 + hh] = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
 }
 
 // wpack[mblk][kstep][tap][lane][8]: lane (r, h) holds W[co = 32 mblk + r][ci = 16 kstep + 8 h + j][tap], j = 0..7, as fp16
@@ -774,6 +881,37 @@ int launch_h8_1x1(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
   SLU_CHECK_LAUNCH();
 }
 
+template <int MB, int NKS>
+int launch_h8_1x1_res(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
+  constexpr size_t lds = (size_t)MB * NKS * 64 * 16 + (size_t)3 * MB * 32 * 4;
+  const long long nblocks = (long long)a.N * a.H * a.W / 32;
+  long long gx = 256 * ((MB * NKS >= 12) ? 2 : ((MB * NKS >= 2) ? 3 : 4));      // as many 4-wave workgroups per CU as the registers allow
+  if (gx * 4 > nblocks) gx = (nblocks + 3) / 4;
+  if (gx <= 0) return SLU_EUNSUPPORTED;
+  hipLaunchKernelGGL((conv1x1_h8_res_kernel<MB, NKS>), dim3((unsigned)gx), dim3(256), lds, st, a, d->resid, d->out);
+  SLU_CHECK_LAUNCH();
+}
+
+// resident-weight streaming form: <= 64 output channels and 1 / 2 / 6 / 12 K-steps (the 1x1 convs of the full- and
+// half-resolution blocks); returns -1 when the shape is not covered
+template <int MB>
+int launch_h8_1x1_res_nks(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
+  switch (a.nks) {
+    case 1:  return launch_h8_1x1_res<MB, 1>(a, d, st);
+    case 2:  return launch_h8_1x1_res<MB, 2>(a, d, st);
+    case 5: case 6:   return launch_h8_1x1_res<MB, 6>(a, d, st);
+    case 10: case 12: return launch_h8_1x1_res<MB, 12>(a, d, st);
+  }
+  return -1;
+}
+
+const char* res_1x1_name(const H8Args& a, char* buf, size_t n) {
+  const int nks = a.nks <= 2 ? a.nks : (a.nks == 5 || a.nks == 6 ? 6 : ((a.nks == 10 || a.nks == 12) ? 12 : 0));
+  if (a.nmblk > 2 || nks == 0) return nullptr;
+  snprintf(buf, n, "conv1x1_h8_res_kernel<%d, %d>", a.nmblk, nks);
+  return buf;
+}
+
 bool any_scale(const slu_conv_h8_desc* d) {
   for (int s = 0; s < d->nsrc; ++s)
     if (d->src[s].scale) return true;
@@ -808,6 +946,10 @@ extern "C" int slu_conv2d_h8_fwd(const slu_conv_h8_desc* d, slu_stream_t stream)
   if (rc != SLU_OK) return rc;
   hipStream_t st = slu_stream(stream);
   if (stream_ok(d, a)) {
+    if (a.nmblk <= 2) {
+      const int rc2 = a.nmblk == 1 ? launch_h8_1x1_res_nks<1>(a, d, st) : launch_h8_1x1_res_nks<2>(a, d, st);
+      if (rc2 != -1) return rc2;
+    }
     if (a.nmblk == 1) return launch_h8_1x1<1, 2>(a, d, st);
     if (a.nmblk == 2) return launch_h8_1x1<2, 2>(a, d, st);
     if (a.nmblk <= 4) return launch_h8_1x1<4, 1>(a, d, st);
@@ -832,6 +974,7 @@ extern "C" int slu_conv2d_h8_kernel_name(const slu_conv_h8_desc* d, char* buf, s
   const int rc = fill_h8(d, a);
   if (rc != SLU_OK || !buf || n == 0) return rc != SLU_OK ? rc : SLU_EINVAL;
   if (stream_ok(d, a)) {
+    if (res_1x1_name(a, buf, n)) return SLU_OK;
     const int mb = a.nmblk == 1 ? 1 : (a.nmblk == 2 ? 2 : (a.nmblk <= 4 ? 4 : 8));
     snprintf(buf, n, "conv1x1_h8_kernel<%d, %d>", mb, mb <= 2 ? 2 : 1);
     return SLU_OK;
