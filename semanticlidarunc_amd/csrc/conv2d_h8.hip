@@ -358,25 +358,58 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 || MB >= 2 || RPW >= 2)
       const uint4* sa = s_a + abase + (WRES ? q * T * 64 : buf * NREC_A);
       half8 sc;
       if constexpr (SCALED) sc = __builtin_bit_cast(half8, s_scale[spar * 64 + 2 * q + hh]);
-      if (!(a.dbg & 1))
+      if (!(a.dbg & 1)) {
+        if constexpr (MB == 1) {
+          // fragments of tap t+1 are read from LDS while the MFMAs of tap t issue (two register sets, one DS read per MFMA
+          // slot); with MB = 2 the second set does not fit in 256 VGPRs next to the 128 accumulator registers
+          half8 af[2][MB], bf[2][NB];
+          auto read_frags = [&](int set, int tap) {
+            const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
 #pragma unroll
-      for (int tap = 0; tap < T; ++tap) {
-        const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
-        half8 af[MB];
+            for (int i = 0; i < MB; ++i) af[set][i] = __builtin_bit_cast(half8, sa[i * a_stride + tap * 64]);
 #pragma unroll
-        for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, sa[i * a_stride + tap * 64]);
+            for (int b = 0; b < NB; ++b) {
+              bf[set][b] = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+              if constexpr (SCALED) bf[set][b] *= sc;
+            }
+          };
+          read_frags(0, 0);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          half8 bf = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
-          if constexpr (SCALED) bf *= sc;
+          for (int tap = 0; tap < T; ++tap) {
+            if (tap + 1 < T) read_frags((tap + 1) & 1, tap + 1);
 #pragma unroll
-          for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acc[i][b], 0, 0, 0);
-        }
-        // ask for an MFMA / LDS-read interleave: each tap's fragment reads are spread between the previous tap's MFMAs
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int k = 0; k < MB * NB; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, (MB + NB + MB * NB - 1) / (MB * NB), 0);
+              for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap & 1][i], bf[tap & 1][b], acc[i][b], 0, 0, 0);
+            if (tap + 1 < T) {
+#pragma unroll
+              for (int k = 0; k < MB * NB; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, (MB + NB + MB * NB - 1) / (MB * NB), 0);
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int tap = 0; tap < T; ++tap) {
+            const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
+            half8 af[MB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, sa[i * a_stride + tap * 64]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              half8 bf = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+              if constexpr (SCALED) bf *= sc;
+#pragma unroll
+              for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acc[i][b], 0, 0, 0);
+            }
+            // ask for an MFMA / LDS-read interleave: each tap's fragment reads are spread between the previous tap's MFMAs
+#pragma unroll
+            for (int k = 0; k < MB * NB; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, (MB + NB + MB * NB - 1) / (MB * NB), 0);
+            }
+          }
         }
       }
       buf ^= 1;
