@@ -19,6 +19,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -122,27 +123,34 @@ template <int STRIDE, bool PRE>
 __device__ __forceinline__ void store_tile_full(const H8Args& a, const f32x16& acc, const float* se, int cl0, int go0, int hh, bool pix_ok, size_t n,
                                                 size_t pix, size_t HW, const uint2* __restrict__ resid, const uint2 (&rv)[4],
                                                 uint2* __restrict__ out, float slope_pre) {
+  // packed fp32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma: two channels per instruction); LeakyReLU as max(t, slope t),
+  // exact for 0 <= slope <= 1 (slope_pre = 1 means "no activation"); the per-channel constants come as 16-byte LDS reads
+  const float4* se4 = reinterpret_cast<const float4*>(se);
+  const float2v sl = {slope_pre, slope_pre};
+  const size_t plane2 = HW * 2;
+  const size_t idx0 = ((n * a.Gout + go0) * HW + pix) * 2 + hh;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    float v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int cl = cl0 + 8 * q + 4 * hh + k;
-      float t = acc[4 * q + k] + se[cl];
-      t = t > 0.0f ? t : t * slope_pre;
-      v[k] = t * se[STRIDE + cl] + se[2 * STRIDE + cl];
-    }
+    const int c4 = (cl0 + 8 * q) / 4 + hh;
+    const float4 bi = se4[c4], ba = se4[STRIDE / 4 + c4], bb = se4[2 * STRIDE / 4 + c4];
+    float2v t0 = {acc[4 * q], acc[4 * q + 1]}, t1 = {acc[4 * q + 2], acc[4 * q + 3]};
+    t0 += float2v{bi.x, bi.y};
+    t1 += float2v{bi.z, bi.w};
+    t0 = __builtin_elementwise_max(t0, t0 * sl);
+    t1 = __builtin_elementwise_max(t1, t1 * sl);
+    t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
+    t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
     const bool ok = pix_ok && go0 + q < a.Gout;
-    const size_t idx = ((n * a.Gout + go0 + q) * HW + pix) * 2 + hh;
+    const size_t idx = idx0 + q * plane2;
     if (resid) {
       const uint2 r = PRE ? rv[q] : *(ok ? resid + idx : reinterpret_cast<const uint2*>(&g_zero_rec));
-      const half2v r0 = __builtin_bit_cast(half2v, r.x), r1 = __builtin_bit_cast(half2v, r.y);
-      v[0] += (float)r0[0]; v[1] += (float)r0[1]; v[2] += (float)r1[0]; v[3] += (float)r1[1];
+      t0 += __builtin_convertvector(__builtin_bit_cast(half2v, r.x), float2v);
+      t1 += __builtin_convertvector(__builtin_bit_cast(half2v, r.y), float2v);
     }
-    *(ok ? out + idx : reinterpret_cast<uint2*>(&g_trash_rec)) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+    *(ok ? out + idx : reinterpret_cast<uint2*>(&g_trash_rec)) =
+        make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v)), __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v)));
   }
 }
-
 
 // one global_load_lds_dwordx4: lane l copies the 16 bytes at its own `gsrc` to LDS address `ldst_wave_base + 16 l`
 #define SLU_GLDS16(gsrc, ldst_wave_base)                                                                  \
@@ -784,6 +792,7 @@ int fill_h8(const slu_conv_h8_desc* d, H8Args& a) {
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return SLU_EINVAL;
   if (d->bn_a && !d->bn_b) return SLU_EINVAL;
   if (d->has_act != 0 && d->has_act != 1) return SLU_EINVAL;
+  if (d->has_act && !(d->slope >= 0.0f && d->slope <= 1.0f)) return SLU_EINVAL;      // LeakyReLU is evaluated as max(v, slope v)
   int g = 0;
   for (int s = 0; s < d->nsrc; ++s) {
     const slu_h8_src& S = d->src[s];
