@@ -169,7 +169,7 @@ __device__ __forceinline__ void store_tile_full(const H8Args& a, const f32x16& a
 // fragments after the LDS read.
 // -----------------------------------------------------------------------------------------------------------
 template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool SCALED, bool WRES, bool F32OUT>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 || MB >= 2 || RPW >= 2) ? 2 : 3) void conv_h8_kernel(const H8Args a, const void* __restrict__ resid,
+__global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 || MB >= 2 || RPW >= 2) ? 2 : 3)) void conv_h8_kernel(const H8Args a, const void* __restrict__ resid,
                                                                                                        void* __restrict__ out) {
   constexpr int NWAVE = WM * WN;
   constexpr int T = KS * KS;
@@ -201,14 +201,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 || MB >= 2 || RPW >= 2)
     t_end = (int)(nt * (w + 1) / nwg);
   }
   if (t_beg >= t_end) return;
-
-  f32x16 acc[MB][NB];
-#pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
 
   if (tid < MBLK * 32) {
     const int co = mblk0 * 32 + tid;
@@ -329,13 +321,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 || MB >= 2 || RPW >= 2)
   uint2 rv[PRE ? NB : 1][4];
 
   for (int tile = t_beg; tile < t_end; ++tile) {
+    f32x16 acc[MB][NB];                                // per tile (not carried around the loop: keeps it in the MFMA registers)
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
     const int spar = (tile - t_beg) & 1;
     if constexpr (SCALED) stage_scales(cur.n, spar);
     for (int q = 0; q < nks; ++q) {
       // Chunk (tile, q) has landed and nobody reads the other buffer any more.  vmcnt counts loads, LDS-DMA and stores in
       // issue order: at a tile's first chunk the only operations younger than the DMA we wait for are the NST stores of the
       // previous tile's epilogue, which may stay in flight (waiting for them would expose the HBM write latency per tile).
-      if (!F32OUT && q == 0 && tile != t_beg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+      if (!F32OUT && q == 0 && tile != t_beg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST < 63 ? NST : 63) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 || MB >= 2 || RPW >= 2)
       half8 sc;
       if constexpr (SCALED) sc = __builtin_bit_cast(half8, s_scale[spar * 64 + 2 * q + hh]);
       if (!(a.dbg & 1)) {
-        if constexpr (MB == 1) {
+        if constexpr (MB == 1 || MB * RPW >= 8) {
           // fragments of tap t+1 are read from LDS while the MFMAs of tap t issue (two register sets, one DS read per MFMA
           // slot); with MB = 2 the second set does not fit in 256 VGPRs next to the 128 accumulator registers
           half8 af[2][MB], bf[2][NB];
@@ -440,12 +439,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 || MB >= 2 || RPW >= 2)
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
     cur = nxt;
   }
 }
@@ -824,7 +817,7 @@ int fill_h8(const slu_conv_h8_desc* d, H8Args& a) {
 template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool SCALED, bool WRES, bool F32OUT = false>
 int launch_h8_k(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
   constexpr int TH = WN * RPW, MBLK = WM * MB, T = KS * KS, NWAVE = WM * WN;
-  constexpr int WAVES_PER_SIMD = (NWAVE >= 8 || MB >= 2 || RPW >= 2) ? 2 : 3;       // the kernel's __launch_bounds__
+  constexpr int WAVES_PER_SIMD = (MB * RPW >= 8) ? 1 : ((NWAVE >= 8 || MB >= 2 || RPW >= 2) ? 2 : 3);       // the kernel's __launch_bounds__
   constexpr size_t nb_alloc = (size_t)((2 * (TH + 2 * PAD) * (64 + 2 * PAD) + 63) / 64) * 64;
   const size_t lds = (size_t)3 * MBLK * 32 * 4 + (SCALED ? 2048 : 0) + 2 * nb_alloc * 16 + (size_t)MBLK * (WRES ? a.nks : 2) * T * 64 * 16;
   if (lds > 160 * 1024) return SLU_EUNSUPPORTED;
