@@ -13,7 +13,6 @@
 //   conv1x1_h8_kernel   1x1 convs: no halo => B operands straight from global memory, weights through LDS
 //   plus layout / pooling / pixel-shuffle helpers at the end of the file.
 #include <stdio.h>
-#include <stdlib.h>
 #include "slu_common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -41,7 +40,6 @@ struct H8Args {
   float slope;
   int out_f32;         // 1: `out` is fp32 NCHW [N][Cout][H][W] (the logits head); 0: h8
   int tiles_x, tiles_y;
-  int dbg;             // development knobs (SLU_H8_DBG): 1 skip MFMAs, 2 skip re-staging, 4 skip the epilogue
 };
 
 struct SrcSel {
@@ -340,10 +338,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (q + 1 < nks) {
-        if (!(a.dbg & 2)) stage(cur, q + 1, buf ^ 1);
+        stage(cur, q + 1, buf ^ 1);
       } else if (tile + 1 < t_end) {
         nxt = decode(tile + 1);
-        if (!(a.dbg & 2)) stage(nxt, 0, buf ^ 1);
+        stage(nxt, 0, buf ^ 1);
       }
       if constexpr (PRE) {
         if (resid && q == nks - 1) {
@@ -365,8 +363,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
       const uint4* sa = s_a + abase + (WRES ? q * T * 64 : buf * NREC_A);
       half8 sc;
       if constexpr (SCALED) sc = __builtin_bit_cast(half8, s_scale[spar * 64 + 2 * q + hh]);
-      if (!(a.dbg & 1)) {
-        if constexpr (MB == 1 || MB * RPW >= 8) {
+      {
+        if constexpr (MB == 1) {
           // fragments of tap t+1 are read from LDS while the MFMAs of tap t issue (two register sets, one DS read per MFMA
           // slot); with MB = 2 the second set does not fit in 256 VGPRs next to the 128 accumulator registers
           half8 af[2][MB], bf[2][NB];
@@ -421,7 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
       }
       buf ^= 1;
     }
-    if (!(a.dbg & 4)) {
+    {
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
         const int ml = wm * MB + i;
@@ -809,8 +807,6 @@ int fill_h8(const slu_conv_h8_desc* d, H8Args& a) {
   a.has_act = d->has_act; a.slope = d->slope;
   a.out_f32 = d->out_f32_nchw ? 1 : 0;
   a.tiles_x = a.tiles_y = 0;
-  const char* dbg = getenv("SLU_H8_DBG");
-  a.dbg = dbg ? atoi(dbg) : 0;
   return SLU_OK;
 }
 
@@ -833,7 +829,6 @@ int launch_h8_k(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
   if (by_lds < per_cu) per_cu = by_lds;
   if (per_cu < 1) per_cu = 1;
   long long gx = (256 * per_cu + gy - 1) / gy;
-  if (const char* f = getenv("SLU_H8_GRIDMUL")) gx = gx * atoi(f);
   if (gx < 8) gx = 8;
   if (gx > nt) gx = nt;
   auto kern = conv_h8_kernel<KS, DIL, PAD, MB, WM, WN, RPW, SCALED, WRES, F32OUT>;
@@ -867,7 +862,6 @@ enum { CFG_M32_TH16 = 0, CFG_M64_TH16, CFG_M128_TH8, CFG_M32_TH8, CFG_M64_TH8, C
 const int CFG_TABLE[CFG_COUNT][4] = {{1, 1, 8, 2}, {2, 1, 8, 2}, {2, 2, 4, 2}, {1, 1, 4, 2}, {2, 1, 4, 2}, {2, 2, 2, 2}, {1, 1, 4, 1}, {2, 1, 4, 1}};
 
 int choose_h8(const H8Args& a) {
-  if (const char* f = getenv("SLU_H8_CFG")) return atoi(f);
   const long long want = 256;
   if (a.nmblk >= 4) {
     if (a.H >= 8 && wg_count(a, 8, 4) >= want) return CFG_M128_TH8;
