@@ -30,7 +30,7 @@ F16X3_MFMA_PEAK_TFLOPS = 2500.0 / 3  # three dense f16 MFMAs (2.5 PFLOP/s) per f
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(model_sd, x_cpu, threads):
+def cpu_baseline(model_sd, x_cpu, threads, passes=T):
     """The oracle (CPU restatement, pinned against the reference) on the host cores: one MC scan
     (T=8 passes of one 64x2048 scan with dropout multipliers + the reduction), after one warm-up pass."""
     from oracle import salsanext as osalsa, uncertainty as ounc
@@ -41,12 +41,12 @@ def cpu_baseline(model_sd, x_cpu, threads):
         t0 = time.perf_counter()
         outs = []
         g = torch.Generator().manual_seed(0)
-        for _ in range(T):
+        for _ in range(passes):
             outs.append(osalsa.salsanext_forward(model_sd, x1, osalsa.draw_dropout_scales(1, 0.2, g)))
         ounc.mc_reduce(torch.stack(outs, 0))
         dt = time.perf_counter() - t0
     return {"value": round(1.0 / dt, 4), "unit": "scans/s", "cores": threads, "kind": "port",
-            "sample": f"1 scan 64x2048x5, T={T} passes + MC reduction, torch-CPU oracle, {dt:.2f} s"}
+            "sample": f"1 scan {x1.shape[2]}x{x1.shape[3]}x5, T={passes} passes + MC reduction, torch-CPU oracle, {dt:.2f} s"}
 
 
 def main():
@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scans", type=int, default=4, help="scans per step per GPU")
+    ap.add_argument("--height", type=int, default=H, help="range-image rows (default: the metric's 64; 128 = BASELINE configs[4])")
+    ap.add_argument("--width", type=int, default=W, help="range-image columns (default: the metric's 2048; 4096 = configs[4])")
+    ap.add_argument("--passes", type=int, default=T, help="MC passes T (default: the metric's 8; 16 = configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shared-prefix", action="store_true",
                     help="MC schedule that computes the layers no active Dropout2d can reach once per scan instead of T times "
@@ -90,13 +93,14 @@ def main():
     model = seeded_model(SalsaNext)
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
-    x_cpu, labels_cpu = synthetic_scan(args.scans, H, W, seed=1234 + rank)
+    Hh, Ww, Tt = args.height, args.width, args.passes
+    x_cpu, labels_cpu = synthetic_scan(args.scans, Hh, Ww, seed=1234 + rank)
     x, labels = x_cpu.to(dev), labels_cpu.to(dev)
     iou, ece = IoUEvaluator(NCLS), ECEAggregator(n_bins=15, mode="probs", ignore_index=0, max_samples=500000)
     torch.manual_seed(100 + rank)
 
     def step(share_prefix=args.shared_prefix):
-        p_bar, h_norm, mi_norm, preds = mc_predict(model, [x], T=T, share_prefix=share_prefix)
+        p_bar, h_norm, mi_norm, preds = mc_predict(model, [x], T=Tt, share_prefix=share_prefix)
         iou.update(preds, labels)
         ece.update(p_bar, labels)
         return h_norm
@@ -167,23 +171,24 @@ def main():
     if rank == 0:
         scans = args.scans * world * args.steps
         out = {
-            "metric": "range-image scans/sec (64x2048, T=8 MC)", "value": round(scans / dt, 3), "unit": "scans/s",
+            "metric": f"range-image scans/sec ({Hh}x{Ww}, T={Tt} MC)", "value": round(scans / dt, 3), "unit": "scans/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "f16x3": "f16x3 (fp32 I/O and accumulate; products as 3 split-fp16 MFMAs)",
                       "f16": "f16 (fp16 activations/weights, fp32 accumulate + epilogue, fp32 logits)"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"SalsaNext MC-dropout T={T} + entropy/MI map + IoU/ECE accumulation, "
-                                   f"{args.scans} scans of {H}x{W}x5 per step per GPU (BASELINE configs[2] shape)",
-                       "scans_per_step_per_gpu": args.scans, "T": T, "parallelism": f"scan-sharded x{world}",
+            "config": {"workload": f"SalsaNext MC-dropout T={Tt} + entropy/MI map + IoU/ECE accumulation, "
+                                   f"{args.scans} scans of {Hh}x{Ww}x5 per step per GPU "
+                                   f"({'BASELINE configs[2] shape' if (Hh, Ww, Tt) == (H, W, T) else 'non-default shape'})",
+                       "scans_per_step_per_gpu": args.scans, "T": Tt, "parallelism": f"scan-sharded x{world}",
                        "mc_schedule": "shared deterministic prefix (3 context blocks + resBlock1 + resBlock2 convs once per scan)"
                                       if args.shared_prefix else "every pass fully recomputed"},
             "parity": {"mIoU_random_labels": round(miou, 6), "ece": round(ece_v, 6)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd_cpu, x_cpu, threads=min(16, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, x_cpu, threads=min(16, os.cpu_count() or 1), passes=Tt)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

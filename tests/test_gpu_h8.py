@@ -224,3 +224,30 @@ def test_mc_shared_prefix_equals_stacked_passes_in_f16(cuda):
         assert out[0].shape == (b, 20, 32, 128) and bool(torch.isfinite(out[1]).all())
     finally:
         sn.set_conv_precision("fp32")
+
+
+def test_ouster_shape_128x4096_T16(cuda):
+    """BASELINE configs[4] shape: one 128x4096 scan against the fp32 oracle, and T=16 MC passes through the shared-prefix
+    schedule against T stacked passes (bit-identical) with finite, normalised uncertainty maps."""
+    model = seeded_model(sn.SalsaNext).to(cuda)
+    sn.set_conv_precision("f16")
+    try:
+        x, _ = synthetic_scan(1, 128, 4096, seed=21)
+        sd = {k: v.cpu() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            want = osalsa.salsanext_forward(sd, x)
+            got = model(x.to(cuda)).cpu()
+        assert float((got - want).abs().max()) <= 1e-3
+        assert float((_entropy(got) - _entropy(want)).abs().max()) <= 1e-3
+        t = 16
+        oscales = osalsa.draw_dropout_scales(t, 0.2, torch.Generator().manual_seed(3))
+        with torch.no_grad():
+            stacked = model.forward_with_dropout_scales(x.repeat(t, 1, 1, 1).to(cuda), oscales)
+            shared = model.forward_mc(x.to(cuda), t, oscales)
+        assert torch.equal(stacked, shared)
+        p_bar, h_norm, mi_norm, preds = ops.mc_reduce(shared.view(t, 1, *shared.shape[1:]))
+        assert bool(torch.isfinite(p_bar).all()) and float((p_bar.sum(1) - 1).abs().max()) <= 1e-5
+        assert float(h_norm.min()) >= 0 and float(h_norm.max()) <= 1 + 1e-6 and float(mi_norm.min()) >= 0
+        assert float((mi_norm - h_norm).max()) <= 1e-6             # MI <= H
+    finally:
+        sn.set_conv_precision("fp32")
