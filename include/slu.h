@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 5
+#define SLU_ABI_VERSION 6
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -287,6 +287,20 @@ int slu_avgpool3s2_h8(const void* x, const float* scale, void* y, int N, int in_
  * x: h8 with Gin blocks at HxW; y: h8 with ceil(2 Gin / 8) blocks at 2Hx2W; scales fp32 [N][8 Gin] / [N][2 Gin] or NULL */
 int slu_pixel_shuffle_h8(const void* x, const float* scale_in, const float* scale_out, void* y, int N, int Gin, int H, int W,
                          slu_stream_t stream);
+
+/* ---- Dirichlet head (the reference's default loss path, configs/SemanticKitti_default.yaml:10) ---------------
+ * alpha = 1 + softplus(scale / T) * softmax(shape) + eps   (probability_helper.py:89-105; trainer.py:533-535 splits the C+1
+ *   output channels into shape = outputs[:, :C] and scale = outputs[:, C:C+1], hence the batch strides in elements)
+ * alpha0 = sum_c alpha + eps, p_hat = alpha / alpha0        (trainer.py:537-538)
+ * entropy   = -sum_c p_hat log(p_hat + eps)                 (get_predictive_entropy :116-121; divide by ln C for _norm :148-153)
+ * aleatoric = -sum_c p_hat (digamma(alpha+1) - digamma(alpha0+1))   (get_aleatoric_uncertainty :124-130); epistemic = entropy - aleatoric
+ * preds = argmax_c alpha.  Every output pointer may be NULL.  C <= 32. */
+int slu_dirichlet_head(const float* shape_logits, long long shape_batch_stride, const float* scale_logits, long long scale_batch_stride,
+                       int B, int C, int HW, float temperature, float eps, float* alpha, float* p_hat, float* entropy, float* aleatoric,
+                       int64_t* preds, slu_stream_t stream);
+/* the same uncertainty measures from a given alpha [B, C, H, W] */
+int slu_dirichlet_uncertainty(const float* alpha, int B, int C, int HW, float eps, float* p_hat, float* entropy, float* aleatoric,
+                              int64_t* preds, slu_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -120,6 +120,9 @@ SIGNATURES = {
     "slu_h8_to_nchw": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_avgpool3s2_h8": (C.c_int, [C.c_void_p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_pixel_shuffle_h8": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_dirichlet_head": (C.c_int, [c_f32p, C.c_longlong, c_f32p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p,
+                                     c_f32p, c_f32p, c_f32p, c_i64p, c_stream]),
+    "slu_dirichlet_uncertainty": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_f32p, c_f32p, c_i64p, c_stream]),
     "slu_lovasz_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_lovasz_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_size_t, c_f32p,
                                  c_f32p, c_f32p, c_stream]),

@@ -123,3 +123,24 @@ def test_ece_golden():
 def test_fixture_files_present():
     with open(os.path.join(GOLDEN, "salsanext_state_dict_keys.json")) as f:
         assert len(json.load(f)) == 51 * 2 + 42 * 5
+
+
+def test_dirichlet_head_matches_reference_golden():
+    """oracle.dirichlet against the vectors tools/gen_golden.py took from the reference's probability_helper."""
+    from oracle import dirichlet as odir
+    g = golden("dirichlet_head_2x21x8x64")
+    outs = torch.from_numpy(g["outputs"])
+    alpha, p_hat, h_norm, preds = odir.head(outs, 20)
+    assert float((alpha - torch.from_numpy(g["alpha"])).abs().max()) == 0.0
+    assert float((p_hat - torch.from_numpy(g["p_hat"])).abs().max()) == 0.0
+    assert float((h_norm - torch.from_numpy(g["H_norm"])).abs().max()) == 0.0
+    assert torch.equal(preds, torch.from_numpy(g["preds"]))
+    assert float((odir.aleatoric(alpha) - torch.from_numpy(g["AU"])).abs().max()) == 0.0
+    assert float((odir.epistemic(alpha) - torch.from_numpy(g["EU"])).abs().max()) == 0.0
+    a2 = odir.alpha_from_shape_and_scale(outs[:, :20], outs[:, 20:21], 2.5, 1e-6)
+    assert float((a2 - torch.from_numpy(g["alpha_T2p5_eps1em6"])).abs().max()) == 0.0
+    # known answers: zero evidence (scale -> -inf) gives alpha = 1 + eps, the uniform p_hat and H_norm = 1
+    flat = torch.zeros(1, 21, 2, 2)
+    flat[:, 20] = -100.0
+    a, p, hn, _ = odir.head(flat, 20)
+    assert float((a - (1.0 + 1e-8)).abs().max()) < 1e-7 and float((p - 0.05).abs().max()) < 1e-7 and float((hn - 1.0).abs().max()) < 1e-6

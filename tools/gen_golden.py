@@ -19,8 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/src"
 sys.path.insert(0, ROOT)
 sys.path.insert(1, REF)
-for stub in ("seaborn", "cv2"):     # used only by plotting helpers of models.evaluator
+for stub in ("seaborn", "cv2"):     # used only by plotting helpers of models.evaluator / models.probability_helper
     sys.modules.setdefault(stub, types.ModuleType(stub))
+sys.modules["cv2"].COLORMAP_TURBO = 20    # default argument of a plotting helper, evaluated at import (probability_helper.py:251)
 
 from baselines.SalsaNext.SalsaNext import SalsaNext as RefSalsaNext   # noqa: E402  (reference)
 from losses.lovasz import LovaszSoftmaxStable as RefLovasz             # noqa: E402
@@ -225,6 +226,28 @@ def main():
     print(f"ECE reference={e_ref:.6f} oracle={e_or:.6f}; MCE {m_ref:.6f}/{m_or:.6f}")
     save("ece_2x20x16x64", probs=pe, labels=lab_m, n=n, ece=e_ref, mce=m_ref,
          acc=np.nan_to_num(stats_ref["acc"].to_numpy()), conf=np.nan_to_num(stats_ref["conf"].to_numpy()))
+    # ---------------- Dirichlet head (models/probability_helper.py) ----------------
+    from models import probability_helper as ref_ph            # reference (cv2 stubbed above; only plotting helpers use it)
+    from oracle import dirichlet as odir
+    g = torch.Generator().manual_seed(77)
+    outs = torch.randn(2, 21, 8, 64, generator=g) * 3.0
+    outs[0, 20] += 25.0                                        # exercises softplus' linear branch (x > 20)
+    shape_l, scale_l = outs[:, :20], outs[:, 20:21]
+    a_ref = ref_ph.to_alpha_concentrations_from_shape_and_scale(shape_l, scale_l)
+    h_ref, au_ref, eu_ref = ref_ph.get_predictive_entropy(a_ref), ref_ph.get_aleatoric_uncertainty(a_ref), ref_ph.get_epistemic_uncertainty(a_ref)
+    hn_ref = ref_ph.get_predictive_entropy_norm(a_ref)
+    a0 = a_ref.sum(dim=1, keepdim=True) + ref_ph.get_eps_value()           # trainer.py:537-538
+    p_ref = a_ref / a0
+    a_or, p_or, hn_or, pr_or = odir.head(outs, 20)
+    for nme, x, y in (("alpha", a_ref, a_or), ("p_hat", p_ref, p_or), ("H_norm", hn_ref, hn_or), ("H", h_ref, odir.predictive_entropy(a_or)),
+                      ("AU", au_ref, odir.aleatoric(a_or)), ("EU", eu_ref, odir.epistemic(a_or))):
+        assert maxdiff(x, y) == 0.0, (nme, maxdiff(x, y))
+    a_t2 = ref_ph.to_alpha_concentrations_from_shape_and_scale(shape_l, scale_l, T=2.5, eps=1e-6)
+    assert maxdiff(a_t2, odir.alpha_from_shape_and_scale(shape_l, scale_l, 2.5, 1e-6)) == 0.0
+    save("dirichlet_head_2x21x8x64", outputs=outs, alpha=a_ref, p_hat=p_ref, H=h_ref, H_norm=hn_ref, AU=au_ref, EU=eu_ref, alpha_T2p5_eps1em6=a_t2,
+         preds=a_ref.argmax(dim=1))
+    print("  oracle.dirichlet == reference probability_helper (0.0)")
+
     # ---------------- ResNet-FPN (models/semanticFCN.py) through a stub torchvision serving oracle.fpn.ResNetRef ----------------
     from oracle import fpn as ofpn
     from semanticlidarunc_amd.fpn import SemanticNetworkWithFPN as MyFPN
