@@ -18,12 +18,13 @@ from .ops import ConvSource
 
 class LayerCfg:
     """Non-tensor description of one fused layer call (plain Python, ignored by autograd)."""
-    __slots__ = ("ksize", "dil", "pad", "slope", "scales", "shuffles", "bn", "cout", "wpack", "wdpack_cache")
+    __slots__ = ("ksize", "dil", "pad", "slope", "scales", "shuffles", "bn", "cout", "wpack", "wdpack_cache", "precision")
 
-    def __init__(self, ksize, dil, pad, slope, scales, shuffles, bn, cout, wpack, wdpack_cache):
+    def __init__(self, ksize, dil, pad, slope, scales, shuffles, bn, cout, wpack, wdpack_cache, precision="fp32"):
         self.ksize, self.dil, self.pad, self.slope = ksize, dil, pad, slope
         self.scales, self.shuffles, self.bn, self.cout = scales, shuffles, bn, cout
         self.wpack, self.wdpack_cache = wpack, wdpack_cache
+        self.precision = precision          # forward conv products: "fp32" (exact MFMA) or "f16x3" (split-fp16, fp32 storage)
 
 
 class ConvLayerFn(torch.autograd.Function):
@@ -31,7 +32,7 @@ class ConvLayerFn(torch.autograd.Function):
     def forward(ctx, cfg: LayerCfg, weight, bias, gamma, beta, resid, *tensors):
         srcs = [ConvSource(t.detach().contiguous(), s, ps) for t, s, ps in zip(tensors, cfg.scales, cfg.shuffles)]
         y = ops.conv2d_fused(srcs, cfg.wpack, cfg.cout, cfg.ksize, cfg.dil, cfg.pad,
-                             bias=None if bias is None else bias.detach(), slope=cfg.slope)
+                             bias=None if bias is None else bias.detach(), slope=cfg.slope, precision=cfg.precision)
         bn: Optional[nn.BatchNorm2d] = cfg.bn
         mean = invstd = None
         train_stats = False
@@ -92,6 +93,8 @@ class ConvLayerFn(torch.autograd.Function):
             dweight = ops.conv2d_wgrad(ops.nchw_to_nhwc(da), ops.gather_nhwc(srcs), n, h, w, cfg.cout, cin, cfg.ksize, cfg.dil, cfg.pad)
         dsrc: List[Optional[torch.Tensor]] = [None] * nsrc
         if any(need[6:6 + nsrc]):
+            # always the exact fp32 kernel: gradients reach 1e-8 and below, outside fp16's range (the split-fp16 products of
+            # the forward are fine because activations are O(1))
             key = (weight.data_ptr(), weight._version)
             if cfg.wdpack_cache.get("key") != key:
                 cfg.wdpack_cache["pack"] = ops.pack_conv_weight(ops.dgrad_weight(weight.detach().contiguous()))

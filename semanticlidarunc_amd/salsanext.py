@@ -34,6 +34,18 @@ _SLOPE = 0.01  # nn.LeakyReLU() default used throughout the reference model
 # Override per process with SLU_CONV_PRECISION or set_conv_precision().
 CONV_PRECISIONS = ("fp32", "f16x3", "f16")
 _CONV_PRECISION = os.environ.get("SLU_CONV_PRECISION", "fp32")
+# Products of the TRAINING forward convs: "fp32" = exact MFMA, "f16x3" = split-fp16 (fp32 storage and accumulation, ~2^-22
+# relative product error; activations are O(1)).  Data- and weight-gradient kernels are always exact fp32: gradients fall
+# below fp16's range.
+_TRAIN_CONV_PRECISION = os.environ.get("SLU_TRAIN_CONV_PRECISION", "fp32")
+
+
+def set_train_conv_precision(precision: str) -> None:
+    global _TRAIN_CONV_PRECISION
+    if precision not in ("fp32", "f16x3"):
+        raise ValueError(f"unknown training conv precision {precision!r}; choose 'fp32' or 'f16x3'")
+    _TRAIN_CONV_PRECISION = precision
+
 
 
 def set_conv_precision(precision: str) -> None:
@@ -108,8 +120,14 @@ class _FusedBlock(nn.Module):
             or (resid is not None and resid.requires_grad) or (bn is not None and bn.weight.requires_grad))
         if wants_grad or (bn is not None and bn.training):
             # autograd node per layer (also the train-mode BatchNorm forward): conv -> stats -> affine
+            wp = p.wpack
+            if _TRAIN_CONV_PRECISION == "f16x3":
+                if p.key16 != wkey:
+                    p.wpack16 = ops.pack_conv_weight_f16x3(conv.weight.detach().contiguous())
+                    p.key16 = wkey
+                wp = p.wpack16
             cfg = LayerCfg(k, conv.dilation[0], conv.padding[0], slope, [s.scale for s in srcs],
-                           [s.pixel_shuffle for s in srcs], bn, conv.out_channels, p.wpack, p.dgrad)
+                           [s.pixel_shuffle for s in srcs], bn, conv.out_channels, wp, p.dgrad, _TRAIN_CONV_PRECISION)
             return ConvLayerFn.apply(cfg, conv.weight, conv.bias, None if bn is None else bn.weight,
                                      None if bn is None else bn.bias, resid, *[s.tensor for s in srcs])
         bn_a, bn_b = self._folded_bn(p, bn)

@@ -28,11 +28,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
+                    help="products of the forward convs (storage and accumulation stay fp32; dgrad / wgrad are always exact fp32)")
     a = ap.parse_args()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rank, _, world = init_from_env(device=dev)
+    from semanticlidarunc_amd import salsanext as sn
+    sn.set_train_conv_precision(a.precision)
     model = seeded_model(SalsaNext).to(dev).train()
     broadcast_parameters(model)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
@@ -70,7 +74,7 @@ def main():
         ms = dt / a.steps * 1e3
         flops = 3 * 124.60e9 * a.batch * (a.height * a.width) / (64 * 2048)
         print(json.dumps({"metric": "training scans/s (fwd + loss + bwd + AdamW)", "value": round(a.batch * world * a.steps / dt, 3),
-                          "unit": "scans/s", "n_gpus": world, "ms_per_step": round(ms, 2), "batch_per_gpu": a.batch, "dtype": "f32",
+                          "unit": "scans/s", "n_gpus": world, "ms_per_step": round(ms, 2), "batch_per_gpu": a.batch, "dtype": "f32" if a.precision == "fp32" else "f32 storage + accumulate, f16x3 products in the forward convs; exact f32 dgrad / wgrad",
                           "conv_tflops_per_gpu(3x fwd flops)": round(flops / (ms * 1e-3) / 1e12, 2), "loss": round(float(loss), 5),
                           "grad_allreduce_mb": round(red.nbytes / 1e6, 1)}))
     if world > 1:
