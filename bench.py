@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scans", type=int, default=4, help="scans per step per GPU")
+    ap.add_argument("--scans", type=int, default=8, help="scans per step per GPU (the reference config batch size for SalsaNext at 64x2048, SemanticKitti_default.yaml:75-78)")
     ap.add_argument("--height", type=int, default=H, help="range-image rows (default: the metric's 64; 128 = BASELINE configs[4])")
     ap.add_argument("--width", type=int, default=W, help="range-image columns (default: the metric's 2048; 4096 = configs[4])")
     ap.add_argument("--passes", type=int, default=T, help="MC passes T (default: the metric's 8; 16 = configs[4])")
