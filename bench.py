@@ -161,7 +161,17 @@ def main():
         achieved = by / sec / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4)}
-    roofline.update({"traffic": None, "launches_per_step": n_l, "avg_launch_us": round(sec / n_l * 1e6, 1),
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (cannot be collected inside this process):
+    # 2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction of MI355X_MICROARCH.md), only when the workload matches
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_f16_traffic_N64.json")
+    if args.precision == "f16" and (Hh, Ww) == (H, W) and not args.shared_prefix and os.path.exists(pmc_file):
+        with open(pmc_file) as f:
+            pmc = json.load(f)
+        if pmc.get("_meta", {}).get("images") == args.scans * Tt and dom in pmc and pmc[dom].get("launches") == n_l:
+            traffic = int((2.0 * pmc[dom]["FETCH_SIZE"] + pmc[dom]["WRITE_SIZE"]) * 1024)
+            traffic_src = "bytes per launch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in profiles/r01/pmc_f16_traffic_N64.json"
+    roofline.update({"traffic": traffic, "traffic_note": traffic_src, "launches_per_step": n_l, "avg_launch_us": round(sec / n_l * 1e6, 1),
                      "algorithmic_gflop_per_launch": round(fl / n_l / 1e9, 3), "algorithmic_mb_per_launch": round(by / n_l / 1e6, 2),
                      "intensity_flop_per_byte": round(fl / by, 1), "ridge_flop_per_byte": round(ridge, 1),
                      "all_convs": {"tflops": round(conv_flops / conv_s / 1e12, 2), "gbs": round(conv_bytes / conv_s / 1e9, 1),

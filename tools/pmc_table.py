@@ -26,7 +26,9 @@ def load(d):
 def main():
     rows = OrderedDict()
     counters = []
-    for d in sys.argv[1:]:
+    args = [a for a in sys.argv[1:] if not a.startswith("--json=")]
+    json_out = next((a[len("--json="):] for a in sys.argv[1:] if a.startswith("--json=")), None)
+    for d in args:
         dur, name, vals = load(d)
         ids = sorted(dur)
         for k, did in enumerate(ids):           # dispatch ids line up across runs of the same deterministic program
@@ -37,6 +39,31 @@ def main():
                 if c not in counters:
                     counters.append(c)
     half = len(rows) // 2
+    starts = [k for k, row in rows.items() if "nchw_to_h8_kernel" in row["name"]]     # first kernel of an f16 forward
+    if starts:
+        half = starts[-1]
+    if json_out:
+        # per kernel name, over the dispatches of the LAST iteration: launches, average duration and counters per launch
+        import json
+        import re
+        agg = {}
+        for k, row in rows.items():
+            if k < half:
+                continue
+            nm = row["name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            nm = re.sub(r"\(.*$", "", nm)
+            a = agg.setdefault(nm, {"launches": 0, "dur_us": 0.0})
+            a["launches"] += 1
+            a["dur_us"] += sum(row["dur"]) / len(row["dur"])
+            for c in counters:
+                a[c] = a.get(c, 0.0) + row.get(c, 0.0)
+        for a in agg.values():
+            n = a["launches"]
+            for key in list(a):
+                if key != "launches":
+                    a[key] = a[key] / n
+        with open(json_out, "w") as f:
+            json.dump(agg, f, indent=1, sort_keys=True)
     print("dur_us " + " ".join(counters) + " kernel")
     for k, row in rows.items():
         if k < half:
