@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture fwd + loss + bwd + AdamW into one HIP graph and replay it (single GPU; removes the ~1000 launch gaps)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
                     help="products of the forward convs (storage and accumulation stay fp32; dgrad / wgrad are always exact fp32)")
     a = ap.parse_args()
@@ -39,7 +41,7 @@ def main():
     sn.set_train_conv_precision(a.precision)
     model = seeded_model(SalsaNext).to(dev).train()
     broadcast_parameters(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, capturable=a.graph)
     red = FlatGradAllReduce(model.parameters())
     red.attach_to_optimizer(opt)
     x, y = synthetic_scan(a.batch, a.height, a.width, seed=1234 + rank)
@@ -61,9 +63,25 @@ def main():
     for _ in range(a.warmup):
         step()
     sync()
+    if a.graph:
+        if world > 1:
+            raise SystemExit("--graph is a single-GPU option (the gradient all-reduce hook is not captured)")
+        graph = torch.cuda.HIPGraph() if hasattr(torch.cuda, "HIPGraph") else torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()                                   # warm-up on the capture stream (lazy attribute / allocator state)
+        torch.cuda.current_stream().wait_stream(side)
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            static_loss = step()
+        run = lambda: (graph.replay(), static_loss)[1]
+    else:
+        run = step
+    sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = step()
+        loss = run()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -76,7 +94,7 @@ def main():
         print(json.dumps({"metric": "training scans/s (fwd + loss + bwd + AdamW)", "value": round(a.batch * world * a.steps / dt, 3),
                           "unit": "scans/s", "n_gpus": world, "ms_per_step": round(ms, 2), "batch_per_gpu": a.batch, "dtype": "f32" if a.precision == "fp32" else "f32 storage + accumulate, f16x3 products in the forward convs; exact f32 dgrad / wgrad",
                           "conv_tflops_per_gpu(3x fwd flops)": round(flops / (ms * 1e-3) / 1e12, 2), "loss": round(float(loss), 5),
-                          "grad_allreduce_mb": round(red.nbytes / 1e6, 1)}))
+                          "grad_allreduce_mb": round(red.nbytes / 1e6, 1), "hip_graph": bool(a.graph)}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
