@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 6
+#define SLU_ABI_VERSION 7
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -301,6 +301,20 @@ int slu_dirichlet_head(const float* shape_logits, long long shape_batch_stride, 
 /* the same uncertainty measures from a given alpha [B, C, H, W] */
 int slu_dirichlet_uncertainty(const float* alpha, int B, int C, int HW, float eps, float* p_hat, float* entropy, float* aleatoric,
                               int64_t* preds, slu_stream_t stream);
+
+/* ---- AUROC of error detection (metrics/auroc.py:36-78) -----------------------------------------------------------
+ * slu_auroc_scores: per pixel, probabilities by mode (0 alpha: a / (sum a + eps); 1 logits: softmax; 2 probs: clamp >= 0, renormalise,
+ *   auroc.py:36-45), prediction = argmax, uncertainty score by score_kind (0 entropy, 1 entropy_norm, 2 mi, 3 mi_norm, 4 1-maxprob;
+ *   mi / mi_norm are the Dirichlet mutual information for mode alpha and fall through to the plain entropy otherwise, :47-63) or
+ *   score_override [B,H,W] verbatim; flags[pix] = 0 correct / 1 error / 2 label == ignore_index (has_ignore).  preds [B,C,H,W], C <= 32.
+ * slu_auroc_compute: AUROC of `n` samples (score, is_error in {0,1}) exactly as :65-78 (sort by score descending, trapezoid over the
+ *   ROC) = sum over negatives of #positives ranked before it / (P N); out3 = {auroc (NaN if P or N is 0), P, N}; optionally the
+ *   samples in sorted order (for ROC curves).  The order among equal scores is arbitrary (as numpy's argsort in the reference). */
+int slu_auroc_scores(const float* preds, const int64_t* labels, const float* score_override, int B, int C, int HW, int mode, int score_kind,
+                     int has_ignore, int64_t ignore_index, float eps, float* scores, uint8_t* flags, slu_stream_t stream);
+size_t slu_auroc_workspace_bytes(long long n);
+int slu_auroc_compute(const float* scores, const uint8_t* is_error, long long n, void* workspace, size_t workspace_bytes, double* out3,
+                      float* sorted_scores, uint8_t* sorted_is_error, slu_stream_t stream);
 
 #ifdef __cplusplus
 }

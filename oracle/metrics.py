@@ -1,13 +1,16 @@
-"""Oracle: confusion-matrix IoU and top-label ECE in numpy.  TEST INFRASTRUCTURE ONLY.
+"""Oracle: confusion-matrix IoU, top-label ECE and error-detection AUROC in numpy / torch CPU.  TEST INFRASTRUCTURE ONLY.
 
-Follows ``src/models/evaluator.py:29-105`` (IoUEvaluator) and ``src/metrics/ece.py:54-168``
-(ECEAggregator: ``_to_probs``, ``update`` without the reservoir cap, ``_stats_df``, ``compute``).
+Follows ``src/models/evaluator.py:29-105`` (IoUEvaluator), ``src/metrics/ece.py:54-168``
+(ECEAggregator: ``_to_probs``, ``update`` without the reservoir cap, ``_stats_df``, ``compute``) and
+``src/metrics/auroc.py:36-78,96-117`` (AUROCAggregator scores, sample selection and the ROC integral).
 Integer work (confusion matrix, bin counts) is exact; pinned by ``tools/gen_golden.py`` against the
 imported reference classes.
 """
 from __future__ import annotations
 
 import numpy as np
+
+_trapz = getattr(np, "trapezoid", None) or np.trapz      # numpy >= 2 renamed it
 
 
 def confusion_matrix(preds, targets, num_classes: int) -> np.ndarray:
@@ -80,3 +83,59 @@ def ece_from_bins(n, acc_s, conf_s):
     conf = np.divide(conf_s, n, out=np.zeros_like(n), where=n > 0)
     gap = np.abs(acc - conf)
     return float(np.sum(n / max(1.0, n.sum()) * gap)), float(np.max(gap[n > 0]))
+
+
+# ---- AUROC of error detection (src/metrics/auroc.py:36-78), restated with torch CPU ops / numpy ------------------------------
+def auroc_samples(preds, labels, mode="alpha", score="entropy_norm", ignore_index=None, eps=1e-12, score_override=None):
+    """(score float32[n], is_error uint8[n]) over valid pixels in NCHW scan order: auroc.py:36-63 (probabilities and score) and
+    :96-117 (prediction, validity mask, error flag)."""
+    import math
+
+    import torch
+    from torch.special import digamma
+    preds = torch.as_tensor(preds)
+    labels = torch.as_tensor(labels)
+    if labels.dim() == 4:
+        labels = labels[:, 0]
+    if mode == "alpha":
+        p = preds / (preds.sum(dim=1, keepdim=True) + eps)
+    elif mode == "logits":
+        p = preds.softmax(dim=1)
+    elif mode == "probs":
+        p = preds.clamp_min(0)
+        p = p / p.sum(dim=1, keepdim=True).clamp_min(eps)
+    else:
+        raise ValueError(mode)
+    pred = p.argmax(dim=1)
+    lab = labels.long()
+    valid = torch.ones_like(lab, dtype=torch.bool) if ignore_index is None else lab != ignore_index
+    if score_override is not None:
+        smap = torch.as_tensor(score_override)
+    elif score in ("entropy", "entropy_norm", "1-maxprob") or mode != "alpha":
+        if score == "1-maxprob":
+            smap = 1.0 - p.max(dim=1).values
+        else:
+            h = -(p.clamp_min(eps) * p.clamp_min(eps).log()).sum(dim=1)
+            smap = h / math.log(p.size(1)) if score == "entropy_norm" else h
+    else:
+        a0 = preds.sum(dim=1, keepdim=True) + eps
+        q = preds / a0
+        h = -(q.clamp_min(eps) * q.clamp_min(eps).log()).sum(dim=1)
+        eh = -(q * (digamma(preds + 1.0) - digamma(a0 + 1.0))).sum(dim=1)
+        mi = h - eh
+        smap = mi / math.log(preds.size(1)) if score == "mi_norm" else mi
+    return smap[valid].reshape(-1).to(torch.float32).numpy(), (pred != lab)[valid].reshape(-1).to(torch.uint8).numpy()
+
+
+def auroc_from_samples(scores, is_error):
+    """auroc.py:65-78: sort by score descending, cumulative sums, trapezoid of TPR over FPR; NaN when a class is empty."""
+    scores = np.asarray(scores)
+    is_error = np.asarray(is_error)
+    order = np.argsort(-scores)
+    y = is_error[order].astype(np.float64)
+    pos, neg = y.sum(), y.size - y.sum()
+    if pos == 0 or neg == 0:
+        return float("nan")
+    tpr = np.concatenate(([0.0], np.cumsum(y) / pos, [1.0]))
+    fpr = np.concatenate(([0.0], np.cumsum(1.0 - y) / neg, [1.0]))
+    return float(_trapz(tpr, fpr))

@@ -346,3 +346,261 @@ extern "C" int slu_lovasz_fwd(const float* probs, const int64_t* labels, int B, 
   }
   SLU_CHECK_LAUNCH();
 }
+
+// =====================================================================================================================
+// AUROC of error detection (replaces src/metrics/auroc.py:36-78 of the reference).
+//
+//   score kernel   per pixel: probabilities by mode (alpha / logits / probs, auroc.py:36-45), argmax, the uncertainty score
+//                  (entropy, entropy_norm, 1-maxprob; Dirichlet mutual information for mode alpha, :47-63), validity.
+//   AUROC          the reference sorts the samples by score (descending), takes cumulative sums and integrates TPR over FPR
+//                  with the trapezoid rule (:65-78).  A negative sample at sorted position i advances FPR by 1/N at height
+//                  TPR_i = (#positives before i) / P and a positive one advances nothing, so
+//                      AUROC = sum over negatives of (#positives ranked before it) / (P N)        -- exact integers.
+//                  The samples go through the same batched LSD radix sort as the Lovasz loss (one "class"); the order among
+//                  equal scores is arbitrary, as it is for numpy's argsort in the reference.
+// =====================================================================================================================
+namespace {
+
+__device__ __forceinline__ float digamma_ge1_f(float x) {      // x >= 1: recurrence to x >= 6, then the asymptotic series
+  float r = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+    if (x < 6.0f) { r -= 1.0f / x; x += 1.0f; }
+  const float inv = 1.0f / x, inv2 = inv * inv;
+  return r + logf(x) - 0.5f * inv - inv2 * (1.0f / 12.0f - inv2 * (1.0f / 120.0f - inv2 * (1.0f / 252.0f)));
+}
+
+// mode: 0 alpha, 1 logits, 2 probs.  kind: 0 entropy, 1 entropy_norm, 2 mi, 3 mi_norm, 4 1-maxprob.
+// flag: 0 correct, 1 error, 2 not valid (label == ignore_index)
+template <int CMAX>
+__global__ __launch_bounds__(256) void auroc_score_kernel(const float* __restrict__ preds, const int64_t* __restrict__ labels,
+                                                          const float* __restrict__ score_override, int B, int C, int HW, int mode, int kind,
+                                                          int has_ignore, int64_t ignore, float eps, float* __restrict__ score_out,
+                                                          uint8_t* __restrict__ flag_out) {
+  const size_t npix = (size_t)B * HW;
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int b = (int)(pix / HW);
+  const int hw = (int)(pix - (size_t)b * HW);
+  const float* src = preds + (size_t)b * C * HW + hw;
+  float x[CMAX], p[CMAX];
+  float m = -INFINITY, sum = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    x[c] = c < C ? src[(size_t)c * HW] : (mode == 1 ? -INFINITY : 0.0f);
+    m = fmaxf(m, x[c]);
+  }
+  if (mode == 1) {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) { p[c] = expf(x[c] - m); sum += p[c]; }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) p[c] = c < C ? p[c] / sum : 0.0f;
+  } else if (mode == 0) {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) sum += x[c];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) p[c] = c < C ? x[c] / (sum + eps) : 0.0f;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) { p[c] = fmaxf(x[c], 0.0f); sum += p[c]; }
+    const float d = fmaxf(sum, eps);
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) p[c] = c < C ? p[c] / d : 0.0f;
+  }
+  float best = -INFINITY;
+  int arg = 0;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c)
+    if (c < C && p[c] > best) { best = p[c]; arg = c; }
+  float score;
+  if (score_override) {
+    score = score_override[pix];
+  } else if (kind == 4) {
+    score = 1.0f - best;
+  } else if (mode == 0 && (kind == 2 || kind == 3)) {
+    // Dirichlet mutual information (auroc.py:55-63): note alpha0 carries eps here, unlike the probabilities above
+    const float a0 = sum + eps;
+    const float dg0 = digamma_ge1_f(a0 + 1.0f);
+    float h = 0.0f, eh = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+        const float q = x[c] / a0;
+        const float qc = fmaxf(q, eps);
+        h -= qc * logf(qc);
+        eh -= q * (digamma_ge1_f(x[c] + 1.0f) - dg0);
+      }
+    score = h - eh;
+    if (kind == 3) score /= logf((float)C);
+  } else {
+    float h = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+        const float qc = fmaxf(p[c], eps);
+        h -= qc * logf(qc);
+      }
+    score = (kind == 1) ? h / logf((float)C) : h;       // every other kind falls through to the plain entropy (auroc.py:53)
+  }
+  const int64_t lab = labels[pix];
+  const bool valid = !has_ignore || lab != ignore;
+  score_out[pix] = score;
+  flag_out[pix] = valid ? (uint8_t)(arg != lab ? 1 : 0) : (uint8_t)2;
+}
+
+// sort key: descending score == ascending key, any finite or infinite float (NaN sorts first)
+__device__ __forceinline__ unsigned desc_key(float s) {
+  const unsigned u = __float_as_uint(s);
+  const unsigned asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ~asc;
+}
+
+__global__ __launch_bounds__(kThreads) void auroc_keygen_kernel(const float* __restrict__ scores, const uint8_t* __restrict__ is_err, long long n,
+                                                                unsigned* __restrict__ keys, unsigned* __restrict__ vals, unsigned* __restrict__ G) {
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+    keys[i] = desc_key(scores[i]);
+    vals[i] = (unsigned)i | (is_err[i] ? 0x80000000u : 0u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) G[0] = 1u;          // the sort kernels skip "classes" whose count is 0
+}
+
+// after the sort: sum over negatives of the number of positives ranked before them (exact, 64-bit)
+__global__ __launch_bounds__(kThreads) void auroc_sum_kernel(const unsigned* __restrict__ vals, long long n, const unsigned* __restrict__ blkfg,
+                                                             unsigned long long* __restrict__ total) {
+  constexpr int kWaves = kThreads / 64;
+  __shared__ unsigned s_w[kWaves];
+  __shared__ unsigned long long s_sum[kWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, blk = blockIdx.x;
+  // a wave owns kItems consecutive 64-element rows of the tile (sorted order == (wave, item, lane))
+  const long long base = (long long)blk * kTile + (long long)wave * (kItems * 64);
+  unsigned fg[kItems];
+  unsigned cnt = 0;
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const long long i = base + it * 64 + lane;
+    fg[it] = i < n ? (vals[i] >> 31) : 0u;
+    cnt += (unsigned)__popcll(__ballot(fg[it]));
+  }
+  if (lane == 0) s_w[wave] = cnt;
+  __syncthreads();
+  unsigned before = blkfg[blk];
+  for (int w = 0; w < wave; ++w) before += s_w[w];
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  unsigned long long acc = 0;
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const long long i = base + it * 64 + lane;
+    const unsigned long long m = __ballot(fg[it]);
+    if (i < n && !fg[it]) acc += before + (unsigned)__popcll(m & lt);
+    before += (unsigned)__popcll(m);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) s_sum[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kWaves; ++w) t += s_sum[w];
+    if (t) atomicAdd(total, t);
+  }
+}
+
+__global__ void auroc_finalize_kernel(const unsigned long long* __restrict__ total, const unsigned* __restrict__ blkfg, const unsigned* __restrict__ vals,
+                                      long long n, int nblk, double* __restrict__ out) {
+  // positives = exclusive prefix of the last tile + its own count
+  unsigned long long pos = blkfg[nblk - 1];
+  for (long long i = (long long)(nblk - 1) * kTile; i < n; ++i) pos += vals[i] >> 31;
+  const double P = (double)pos, N = (double)(n - (long long)pos);
+  out[1] = P;
+  out[2] = N;
+  out[0] = (pos == 0 || (long long)pos == n) ? (double)NAN : (double)*total / (P * N);
+}
+
+__global__ __launch_bounds__(kThreads) void auroc_unsort_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, long long n,
+                                                                float* __restrict__ scores, uint8_t* __restrict__ is_err) {
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+    const unsigned asc = ~keys[i];
+    const unsigned m = (unsigned)((int)asc >> 31);                   // all ones for a non-negative score
+    reinterpret_cast<unsigned*>(scores)[i] = asc ^ ~(m & 0x7FFFFFFFu);
+    is_err[i] = (uint8_t)(vals[i] >> 31);
+  }
+}
+
+size_t auroc_carve(char* base, long long n, Ws* ws, unsigned long long** total) {
+  const int nblk = nblk_of(n);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+  char* g = take(sizeof(unsigned));
+  char* t = take(sizeof(unsigned long long));
+  char* k0 = take((size_t)n * 4); char* k1 = take((size_t)n * 4);
+  char* v0 = take((size_t)n * 4); char* v1 = take((size_t)n * 4);
+  char* h = take((size_t)256 * nblk * 4);
+  char* bf = take((size_t)nblk * 4);
+  if (ws) {
+    ws->G = (unsigned*)g; ws->loss_c = nullptr;
+    ws->keys[0] = (unsigned*)k0; ws->keys[1] = (unsigned*)k1; ws->vals[0] = (unsigned*)v0; ws->vals[1] = (unsigned*)v1;
+    ws->hist = (unsigned*)h; ws->blkfg = (unsigned*)bf;
+    *total = (unsigned long long*)t;
+  }
+  return off;
+}
+
+}  // namespace
+
+extern "C" int slu_auroc_scores(const float* preds, const int64_t* labels, const float* score_override, int B, int C, int HW, int mode, int score_kind,
+                                int has_ignore, int64_t ignore_index, float eps, float* scores, uint8_t* flags, slu_stream_t stream) {
+  if (!preds || !labels || !scores || !flags || B <= 0 || C <= 0 || HW <= 0) return SLU_EINVAL;
+  if (mode < 0 || mode > 2 || score_kind < 0 || score_kind > 4) return SLU_EINVAL;
+  if (C > 32) return SLU_EUNSUPPORTED;
+  const size_t npix = (size_t)B * HW;
+  const unsigned nb = (unsigned)((npix + 255) / 256);
+  if (C <= 20)
+    hipLaunchKernelGGL(auroc_score_kernel<20>, dim3(nb), dim3(256), 0, slu_stream(stream), preds, labels, score_override, B, C, HW, mode, score_kind,
+                       has_ignore, ignore_index, eps, scores, flags);
+  else
+    hipLaunchKernelGGL(auroc_score_kernel<32>, dim3(nb), dim3(256), 0, slu_stream(stream), preds, labels, score_override, B, C, HW, mode, score_kind,
+                       has_ignore, ignore_index, eps, scores, flags);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" size_t slu_auroc_workspace_bytes(long long n) {
+  if (n <= 0) return 0;
+  return auroc_carve(nullptr, n, nullptr, nullptr);
+}
+
+extern "C" int slu_auroc_compute(const float* scores, const uint8_t* is_error, long long n, void* workspace, size_t workspace_bytes, double* out3,
+                                 float* sorted_scores, uint8_t* sorted_is_error, slu_stream_t stream) {
+  if (!scores || !is_error || !workspace || !out3 || n <= 0) return SLU_EINVAL;
+  if (n >= (1ll << 31)) return SLU_EUNSUPPORTED;
+  if ((sorted_scores == nullptr) != (sorted_is_error == nullptr)) return SLU_EINVAL;
+  Ws ws;
+  unsigned long long* total = nullptr;
+  if (auroc_carve((char*)workspace, n, &ws, &total) > workspace_bytes) return SLU_EINVAL;
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return SLU_EINVAL;
+  hipStream_t st = slu_stream(stream);
+  const int nblk = nblk_of(n);
+  if (hipMemsetAsync(ws.G, 0, align256(sizeof(unsigned)) + sizeof(unsigned long long), st) != hipSuccess) return SLU_ELAUNCH;
+  const unsigned kg = (unsigned)((n + kThreads - 1) / kThreads > 1024 ? 1024 : (n + kThreads - 1) / kThreads);
+  hipLaunchKernelGGL(auroc_keygen_kernel, dim3(kg), dim3(kThreads), 0, st, scores, is_error, n, ws.keys[0], ws.vals[0], ws.G);
+  int cur = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 8 * pass;
+    hipLaunchKernelGGL(hist_kernel, dim3(nblk, 1), dim3(kThreads), 0, st, ws.keys[cur], n, nblk, shift, ws.G, ws.hist);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, st, ws.hist, nblk, ws.G);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk, 1), dim3(kThreads), 0, st, ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1], n, nblk,
+                       shift, ws.G, ws.hist);
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(fgcount_kernel, dim3(nblk, 1), dim3(kThreads), 0, st, ws.vals[cur], n, nblk, ws.G, ws.blkfg);
+  hipLaunchKernelGGL(fgscan_kernel, dim3(1), dim3(256), 0, st, ws.blkfg, nblk, ws.G);
+  hipLaunchKernelGGL(auroc_sum_kernel, dim3(nblk), dim3(kThreads), 0, st, ws.vals[cur], n, ws.blkfg, total);
+  hipLaunchKernelGGL(auroc_finalize_kernel, dim3(1), dim3(1), 0, st, total, ws.blkfg, ws.vals[cur], n, nblk, out3);
+  if (sorted_scores) {
+    // the sorted sample list (descending score) for ROC curves: undo the key transform, keep the error flag
+    hipLaunchKernelGGL(auroc_unsort_kernel, dim3(kg), dim3(kThreads), 0, st, ws.keys[cur], ws.vals[cur], n, sorted_scores, sorted_is_error);
+  }
+  SLU_CHECK_LAUNCH();
+}

@@ -648,3 +648,50 @@ def row_softmax_mul(score, value):
     out = torch.empty_like(value)
     check(_lib.load().slu_row_softmax_mul(score.data_ptr(), value.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "slu_row_softmax_mul")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# AUROC of error detection (metrics/auroc.py of the reference)
+# ------------------------------------------------------------------------------------------------
+AUROC_MODES = {"alpha": 0, "logits": 1, "probs": 2}
+AUROC_SCORES = {"entropy": 0, "entropy_norm": 1, "mi": 2, "mi_norm": 3, "1-maxprob": 4}
+
+
+def auroc_scores(preds: torch.Tensor, labels: torch.Tensor, mode: str, score: str, ignore_index=None, eps: float = 1e-12,
+                 score_override: Optional[torch.Tensor] = None):
+    """(score[B,H,W] fp32, flag[B,H,W] uint8: 0 correct / 1 error / 2 ignored) -- slu_auroc_scores."""
+    _req(preds, "preds")
+    _req(labels, "labels", torch.int64)
+    if preds.dim() != 4 or tuple(labels.shape) != (preds.shape[0], preds.shape[2], preds.shape[3]):
+        raise RuntimeError(f"auroc_scores: preds [B,C,H,W] / labels [B,H,W] expected, got {tuple(preds.shape)} / {tuple(labels.shape)}")
+    if mode not in AUROC_MODES or score not in AUROC_SCORES:
+        raise ValueError(f"auroc_scores: unknown mode {mode!r} or score {score!r}")
+    b, c, h, w = preds.shape
+    if score_override is not None:
+        _req(score_override, "score_override")
+        if tuple(score_override.shape) != (b, h, w):
+            raise RuntimeError(f"score_override: expected {(b, h, w)}, got {tuple(score_override.shape)}")
+    s = torch.empty((b, h, w), dtype=torch.float32, device=preds.device)
+    f = torch.empty((b, h, w), dtype=torch.uint8, device=preds.device)
+    check(_lib.load().slu_auroc_scores(preds.data_ptr(), labels.data_ptr(), _ptr(score_override), b, c, h * w, AUROC_MODES[mode], AUROC_SCORES[score],
+                                       0 if ignore_index is None else 1, 0 if ignore_index is None else int(ignore_index), float(eps),
+                                       s.data_ptr(), f.data_ptr(), _stream()), "slu_auroc_scores")
+    return s, f
+
+
+def auroc_from_samples(scores: torch.Tensor, is_error: torch.Tensor, want_sorted: bool = False):
+    """AUROC of 1-D device samples (score fp32, is_error uint8 in {0,1}) -> (auroc, P, N[, sorted_scores, sorted_is_error])."""
+    _req(scores, "scores")
+    _req(is_error, "is_error", torch.uint8)
+    if scores.dim() != 1 or scores.shape != is_error.shape or scores.numel() == 0:
+        raise RuntimeError("auroc_from_samples: two equally long, non-empty 1-D tensors expected")
+    lib = _lib.load()
+    n = scores.numel()
+    ws = torch.empty(lib.slu_auroc_workspace_bytes(n), dtype=torch.uint8, device=scores.device)
+    out = torch.empty(3, dtype=torch.float64, device=scores.device)
+    ss = torch.empty_like(scores) if want_sorted else None
+    se = torch.empty_like(is_error) if want_sorted else None
+    check(lib.slu_auroc_compute(scores.data_ptr(), is_error.data_ptr(), n, ws.data_ptr(), ws.numel(), out.data_ptr(), _ptr(ss), _ptr(se), _stream()),
+          "slu_auroc_compute")
+    a, p, nn_ = (float(v) for v in out.cpu())
+    return (a, int(p), int(nn_), ss, se) if want_sorted else (a, int(p), int(nn_))

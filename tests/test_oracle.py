@@ -144,3 +144,24 @@ def test_dirichlet_head_matches_reference_golden():
     flat[:, 20] = -100.0
     a, p, hn, _ = odir.head(flat, 20)
     assert float((a - (1.0 + 1e-8)).abs().max()) < 1e-7 and float((p - 0.05).abs().max()) < 1e-7 and float((hn - 1.0).abs().max()) < 1e-6
+
+
+def test_auroc_golden_and_known_answers():
+    """oracle.metrics.auroc_* against the values tools/gen_golden.py took from the reference's AUROCAggregator."""
+    g = golden("auroc_2x20x16x64")
+    labs = torch.from_numpy(g["labels"])
+    inputs = {"logits": torch.from_numpy(g["logits"]), "alpha": torch.from_numpy(g["alpha"]), "probs": torch.from_numpy(g["logits"]).softmax(1)}
+    for key in g.files:
+        if not key.startswith("auroc:") or key == "auroc:capped1500":
+            continue
+        mode, score, src = key[len("auroc:"):].split("|")
+        ov = torch.from_numpy(g["override"]) if src == "override" else None
+        s1, e1 = ometrics.auroc_samples(inputs[mode], labs, mode, score, 0, 1e-12, ov)
+        s2, e2 = ometrics.auroc_samples(inputs[mode].flip(0), labs.flip(0), mode, score, 0, 1e-12, None if ov is None else ov.flip(0))
+        a = ometrics.auroc_from_samples(np.concatenate([s1, s2]), np.concatenate([e1, e2]))
+        assert a == float(g[key]) and s1.size + s2.size == int(g["nsamples:" + key[len("auroc:"):]])
+    # hand-derived: perfectly separated scores give 1, reversed 0, one inversion among 2 x 2 gives 3/4
+    assert ometrics.auroc_from_samples(np.array([0.9, 0.8, 0.2, 0.1]), np.array([1, 1, 0, 0])) == 1.0
+    assert ometrics.auroc_from_samples(np.array([0.9, 0.8, 0.2, 0.1]), np.array([0, 0, 1, 1])) == 0.0
+    assert ometrics.auroc_from_samples(np.array([0.9, 0.2, 0.8, 0.1]), np.array([1, 1, 0, 0])) == 0.75
+    assert np.isnan(ometrics.auroc_from_samples(np.array([0.3, 0.2]), np.array([1, 1])))

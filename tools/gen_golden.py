@@ -248,6 +248,46 @@ def main():
          preds=a_ref.argmax(dim=1))
     print("  oracle.dirichlet == reference probability_helper (0.0)")
 
+    # ---------------- AUROC of error detection (metrics/auroc.py) ----------------
+    import tempfile
+    from metrics.auroc import AUROCAggregator as RefAUROC              # reference
+    g = torch.Generator().manual_seed(91)
+    labs = torch.randint(0, 20, (2, 16, 64), generator=g)
+    labs[torch.rand(2, 16, 64, generator=g) < 0.15] = 0                 # ignored pixels
+    logit = torch.randn(2, 20, 16, 64, generator=g) * 2.0
+    logit.scatter_add_(1, labs[:, None], torch.full((2, 1, 16, 64), 2.5))   # mostly-right predictions
+    alpha_in = torch.nn.functional.softplus(logit) + 1.0
+    probs_in = logit.softmax(1)
+    override = torch.rand(2, 16, 64, generator=g)
+    out = {"labels": labs.numpy(), "logits": logit.numpy(), "alpha": alpha_in.numpy(), "override": override.numpy()}
+    cases = [("alpha", "entropy_norm", alpha_in, None), ("alpha", "mi_norm", alpha_in, None), ("alpha", "mi", alpha_in, None),
+             ("alpha", "1-maxprob", alpha_in, None), ("logits", "entropy", logit, None), ("logits", "mi_norm", logit, None),
+             ("probs", "entropy_norm", probs_in, None), ("probs", "1-maxprob", probs_in, None), ("logits", "entropy_norm", logit, override)]
+    for mode, score, inp, ov in cases:
+        agg = RefAUROC(mode=mode, score=score, ignore_index=0)
+        agg.update(inp, labs, score_override=ov)
+        agg.update(inp.flip(0), labs.flip(0)[:, None], score_override=None if ov is None else ov.flip(0))      # [B,1,H,W] labels
+        with tempfile.TemporaryDirectory() as td:
+            a_ref = agg.compute(save_plot_path=os.path.join(td, "roc.png"))[0]
+        s1, e1 = ometrics.auroc_samples(inp, labs, mode, score, 0, 1e-12, ov)
+        s2, e2 = ometrics.auroc_samples(inp.flip(0), labs.flip(0), mode, score, 0, 1e-12, None if ov is None else ov.flip(0))
+        so, eo = np.concatenate([s1, s2]), np.concatenate([e1, e2])
+        assert np.array_equal(so, agg._scores.numpy()) and np.array_equal(eo, agg._is_error.numpy()), (mode, score)
+        a_or = ometrics.auroc_from_samples(so, eo)
+        assert a_or == a_ref, (mode, score, a_or, a_ref)
+        tag = f"{mode}|{score}|{'override' if ov is not None else 'own'}"
+        out["auroc:" + tag] = np.float64(a_ref)
+        out["nsamples:" + tag] = np.int64(so.size)
+    # reservoir cap: three updates against max_samples = 1500 (fill, then probabilistic replacement), numpy seed 0
+    agg = RefAUROC(mode="logits", score="entropy_norm", ignore_index=0, max_samples=1500, seed=0)
+    for k in range(3):
+        agg.update(logit.roll(k, 0) + 0.1 * k, labs.roll(k, 0))
+    with tempfile.TemporaryDirectory() as td:
+        out["auroc:capped1500"] = np.float64(agg.compute(save_plot_path=os.path.join(td, "roc.png"))[0])
+    out["capped_scores_sorted"] = np.sort(agg._scores.numpy())
+    save("auroc_2x20x16x64", **out)
+    print("  oracle.metrics.auroc_* == reference AUROCAggregator (samples and AUROC identical)")
+
     # ---------------- ResNet-FPN (models/semanticFCN.py) through a stub torchvision serving oracle.fpn.ResNetRef ----------------
     from oracle import fpn as ofpn
     from semanticlidarunc_amd.fpn import SemanticNetworkWithFPN as MyFPN
