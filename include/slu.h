@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 7
+#define SLU_ABI_VERSION 8
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -315,6 +315,16 @@ int slu_auroc_scores(const float* preds, const int64_t* labels, const float* sco
 size_t slu_auroc_workspace_bytes(long long n);
 int slu_auroc_compute(const float* scores, const uint8_t* is_error, long long n, void* workspace, size_t workspace_bytes, double* out3,
                       float* sorted_scores, uint8_t* sorted_is_error, slu_stream_t stream);
+
+/* ---- accuracy vs uncertainty bins (models/evaluator.py:640-749 UncertaintyAccuracyAggregator) ---------------------
+ * slu_ua_samples: u_out = clamp(uncertainty, 0, 1); flags = 1 label == pred / 0 otherwise / 2 label in ignore_ids (:659-673).
+ * slu_binned_counts: count[b] += #samples in bin b, n_correct[b] += #correct ones, bins as np.histogram(u, bins=edges) (:733-739):
+ *   [e_b, e_b+1), the last one closed, values outside [e_0, e_K] dropped; edges float32 [n_bins + 1] on the device, n_bins <= 256;
+ *   count / n_correct int64 [n_bins], accumulated (zero them first). */
+int slu_ua_samples(const int64_t* labels, const int64_t* preds, const float* uncertainty, long long n, const int64_t* ignore_ids, int n_ignore,
+                   float* u_out, uint8_t* flags, slu_stream_t stream);
+int slu_binned_counts(const float* u, const uint8_t* correct, long long n, const float* edges, int n_bins, int64_t* count, int64_t* n_correct,
+                      slu_stream_t stream);
 
 #ifdef __cplusplus
 }

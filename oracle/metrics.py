@@ -139,3 +139,39 @@ def auroc_from_samples(scores, is_error):
     tpr = np.concatenate(([0.0], np.cumsum(y) / pos, [1.0]))
     fpr = np.concatenate(([0.0], np.cumsum(1.0 - y) / neg, [1.0]))
     return float(_trapz(tpr, fpr))
+
+
+# ---- accuracy vs uncertainty bins (src/models/evaluator.py:640-749 UncertaintyAccuracyAggregator) --------------------------------
+def ua_samples(labels, preds, uncertainty, ignore_ids=()):
+    """(u float32[n] clamped to [0,1], correct uint8[n]) in scan order, labels in ignore_ids dropped (evaluator.py:659-673)."""
+    lab = np.asarray(labels).astype(np.int64).reshape(-1)
+    prd = np.asarray(preds).astype(np.int64).reshape(-1)
+    unc = np.clip(np.asarray(uncertainty).astype(np.float32).reshape(-1), 0.0, 1.0)
+    if len(ignore_ids):
+        mask = ~np.isin(lab, np.asarray(list(ignore_ids), dtype=np.int64))
+        lab, prd, unc = lab[mask], prd[mask], unc[mask]
+    return unc, (lab == prd).astype(np.uint8)
+
+
+def ua_make_bins(num_bins=None, bin_width=None, bin_edges=None):
+    """evaluator.py:708-724: float32 edges covering [0, 1]; priority bin_edges > bin_width > num_bins (default 10)."""
+    if bin_edges is not None:
+        edges = np.asarray(bin_edges, dtype=np.float32).copy()
+    elif bin_width is not None:
+        edges = np.linspace(0.0, 1.0, max(1, int(round(1.0 / float(bin_width)))) + 1, dtype=np.float32)
+    else:
+        edges = np.linspace(0.0, 1.0, (int(num_bins) if num_bins is not None else 10) + 1, dtype=np.float32)
+    edges[0] = 0.0
+    edges[-1] = 1.0
+    assert np.all(np.diff(edges) > 0), "bin edges must be strictly increasing"
+    return edges
+
+
+def ua_binned(u, correct, edges):
+    """(n int[K], accuracy float[K] with NaN for empty bins, pct float[K]) -- evaluator.py:733-740."""
+    u = np.asarray(u, dtype=np.float32)
+    c = np.asarray(correct).astype(np.float32)
+    n = np.histogram(u, bins=edges)[0].astype(int)
+    csum = np.histogram(u, bins=edges, weights=c)[0]
+    acc = np.divide(csum, n, out=np.full_like(csum, np.nan, dtype=float), where=n > 0)
+    return n, acc, 100.0 * n / max(1, u.size)

@@ -118,6 +118,50 @@ inline unsigned grid_for(size_t n, unsigned cap) {
   return (unsigned)(nb > cap ? cap : (nb ? nb : 1));
 }
 
+
+// models/evaluator.py:659-673 (UncertaintyAccuracyAggregator.update): u = clamp(uncertainty, 0, 1), flag = label == pred, pixels whose
+// label is in ignore_ids dropped.  flag: 0 wrong, 1 correct, 2 ignored.
+__global__ __launch_bounds__(256) void ua_samples_kernel(const int64_t* __restrict__ labels, const int64_t* __restrict__ preds,
+                                                         const float* __restrict__ unc, size_t n, const int64_t* __restrict__ ignore_ids,
+                                                         int n_ignore, float* __restrict__ u_out, uint8_t* __restrict__ flag_out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int64_t lab = labels[i];
+    bool ign = false;
+    for (int k = 0; k < n_ignore; ++k) ign |= lab == ignore_ids[k];
+    u_out[i] = fminf(fmaxf(unc[i], 0.0f), 1.0f);
+    flag_out[i] = ign ? (uint8_t)2 : (uint8_t)(lab == preds[i] ? 1 : 0);
+  }
+}
+
+// models/evaluator.py:733-739: np.histogram(u, bins=edges) and the same with weights = correct, for arbitrary strictly increasing
+// float32 edges: bin i = [e_i, e_{i+1}), the last one closed, values outside [e_0, e_K] dropped.  K <= 256.
+__global__ __launch_bounds__(256) void binned_counts_kernel(const float* __restrict__ u, const uint8_t* __restrict__ correct, size_t n,
+                                                            const float* __restrict__ edges, int K, unsigned long long* __restrict__ count,
+                                                            unsigned long long* __restrict__ n_correct) {
+  __shared__ unsigned s_n[256], s_ok[256];
+  __shared__ float s_edge[257];
+  s_n[threadIdx.x] = 0;
+  s_ok[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i <= K; i += blockDim.x) s_edge[i] = edges[i];
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = u[i];
+    if (!(v >= s_edge[0] && v <= s_edge[K])) continue;
+    int lo = 0, hi = K;                     // largest b with e_b <= v (b < K), the right edge folded into the last bin
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (v >= s_edge[mid]) lo = mid; else hi = mid;
+    }
+    atomicAdd(&s_n[lo], 1u);
+    if (correct[i]) atomicAdd(&s_ok[lo], 1u);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < K && s_n[threadIdx.x]) {
+    atomicAdd(&count[threadIdx.x], (unsigned long long)s_n[threadIdx.x]);
+    atomicAdd(&n_correct[threadIdx.x], (unsigned long long)s_ok[threadIdx.x]);
+  }
+}
+
 }  // namespace
 
 extern "C" int slu_confusion_update(const int64_t* preds, const int64_t* targets, int64_t n, int C, int64_t* confmat,
@@ -156,5 +200,22 @@ extern "C" int slu_softmax_nll_fwd(const float* logits, const int64_t* labels, i
   else
     hipLaunchKernelGGL(softmax_nll_kernel<32>, dim3(g), dim3(256), 0, slu_stream(stream), logits, labels, B, C, HW, clampv, probs,
                        nll_sum);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_ua_samples(const int64_t* labels, const int64_t* preds, const float* uncertainty, long long n, const int64_t* ignore_ids,
+                              int n_ignore, float* u_out, uint8_t* flags, slu_stream_t stream) {
+  if (!labels || !preds || !uncertainty || !u_out || !flags || n <= 0 || n_ignore < 0 || (n_ignore > 0 && !ignore_ids)) return SLU_EINVAL;
+  hipLaunchKernelGGL(ua_samples_kernel, dim3(grid_for((size_t)n, 4096)), dim3(256), 0, slu_stream(stream), labels, preds, uncertainty, (size_t)n,
+                     ignore_ids, n_ignore, u_out, flags);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_binned_counts(const float* u, const uint8_t* correct, long long n, const float* edges, int n_bins, int64_t* count,
+                                 int64_t* n_correct, slu_stream_t stream) {
+  if (!u || !correct || !edges || !count || !n_correct || n <= 0 || n_bins <= 0) return SLU_EINVAL;
+  if (n_bins > 256) return SLU_EUNSUPPORTED;
+  hipLaunchKernelGGL(binned_counts_kernel, dim3(grid_for((size_t)n, 2048)), dim3(256), 0, slu_stream(stream), u, correct, (size_t)n, edges, n_bins,
+                     reinterpret_cast<unsigned long long*>(count), reinterpret_cast<unsigned long long*>(n_correct));
   SLU_CHECK_LAUNCH();
 }

@@ -1,4 +1,4 @@
-"""Mirror of the reference's ``IoUEvaluator`` (src/models/evaluator.py:29-105).
+"""Mirrors of the reference's ``IoUEvaluator`` (src/models/evaluator.py:29-105) and ``UncertaintyAccuracyAggregator`` (:640-869).
 
 ``update`` accumulates the [C,C] int64 confusion matrix (rows = ground truth) with an LDS-histogram
 HIP kernel on the device the predictions live on -- the reference first copies both int64 maps to
@@ -69,3 +69,141 @@ class IoUEvaluator:
             miou = float("nan")
         out["mIoU"] = miou
         return miou, out
+
+
+
+class UncertaintyAccuracyAggregator:
+    """Accuracy per uncertainty bin (reference evaluator.py:640-869), with the (uncertainty, correct) samples kept on the
+    DEVICE: ``update`` runs one HIP kernel (clamp, comparison, ignore mask) instead of three device-to-host copies per batch,
+    ``binned_accuracy`` is a device histogram with ``np.histogram`` semantics, and the numpy-seeded reservoir cap draws the same
+    indices as the reference and applies them to the device buffers."""
+
+    def __init__(self, max_samples=None, seed: int = 0):
+        self.max_samples = max_samples
+        self.rng = np.random.default_rng(seed)
+        self.reset()
+
+    def reset(self):
+        self._uncert = None      # fp32 device tensor, values in [0, 1]
+        self._correct = None     # uint8 device tensor, 1 = correct
+        self._seen = 0
+
+    def _count(self) -> int:
+        return 0 if self._uncert is None else self._uncert.numel()
+
+    def _append(self, unc, corr):
+        self._uncert = unc if self._uncert is None else torch.cat([self._uncert, unc])
+        self._correct = corr if self._correct is None else torch.cat([self._correct, corr])
+
+    @torch.no_grad()
+    def update(self, labels: torch.Tensor, preds: torch.Tensor, uncertainty: torch.Tensor, ignore_ids=()):
+        assert labels.shape == preds.shape == uncertainty.shape, "shapes must match"
+        u, flag = ops.ua_samples(labels.detach().to(torch.int64).contiguous(), preds.detach().to(torch.int64).contiguous(),
+                                 uncertainty.detach().to(torch.float32).contiguous(), tuple(ignore_ids))
+        if len(tuple(ignore_ids)):
+            mask = flag != 2
+            if not bool(mask.any()):
+                return
+            unc, corr = u[mask], flag[mask]
+        else:
+            unc, corr = u, flag
+        if self.max_samples is None:
+            self._append(unc, corr)
+            self._seen += unc.numel()
+            return
+        n_new = unc.numel()                         # reservoir-like cap, evaluator.py:681-700
+        self._seen += n_new
+        if self._count() < self.max_samples:
+            take = min(self.max_samples - self._count(), n_new)
+            if take < n_new:
+                idx = torch.from_numpy(self.rng.choice(n_new, size=take, replace=False)).to(unc.device)
+                unc, corr = unc[idx], corr[idx]
+            self._append(unc, corr)
+        else:
+            p = min(1.0, float(self.max_samples) / float(self._seen + 1e-9))
+            keep = torch.from_numpy(self.rng.random(n_new) < p)
+            if keep.any():
+                keep = keep.to(unc.device)
+                unc, corr = unc[keep], corr[keep]
+                replace_idx = torch.from_numpy(self.rng.choice(self.max_samples, size=unc.numel(), replace=False)).to(unc.device)
+                self._uncert[replace_idx] = unc
+                self._correct[replace_idx] = corr
+
+    def make_bins(self, num_bins=None, bin_width=None, bin_edges=None) -> np.ndarray:
+        """Strictly increasing float32 edges covering [0, 1]; priority bin_edges > bin_width > num_bins (evaluator.py:708-724)."""
+        if bin_edges is not None:
+            edges = np.asarray(bin_edges, dtype=np.float32).copy()
+        elif bin_width is not None:
+            edges = np.linspace(0.0, 1.0, max(1, int(round(1.0 / float(bin_width)))) + 1, dtype=np.float32)
+        else:
+            edges = np.linspace(0.0, 1.0, (int(num_bins) if num_bins is not None else 10) + 1, dtype=np.float32)
+        edges[0] = 0.0
+        edges[-1] = 1.0
+        assert np.all(np.diff(edges) > 0), "bin edges must be strictly increasing"
+        return edges
+
+    def binned_accuracy(self, num_bins: int = 10, bin_width=None, bin_edges=None):
+        """DataFrame [low, high, label, n, pct, accuracy]; empty bins: n = 0, accuracy = NaN, pct = 0 (evaluator.py:726-749)."""
+        import pandas as pd
+        if self._count() == 0:
+            return pd.DataFrame(columns=["low", "high", "label", "n", "pct", "accuracy"])
+        edges = self.make_bins(num_bins=num_bins, bin_width=bin_width, bin_edges=bin_edges)
+        cnt, ok = ops.binned_counts(self._uncert.contiguous(), self._correct.contiguous(), torch.from_numpy(edges).to(self._uncert.device))
+        n = cnt.cpu().numpy().astype(int)
+        csum = ok.cpu().numpy().astype(np.float64)
+        acc = np.divide(csum, n, out=np.full_like(csum, np.nan, dtype=float), where=n > 0)
+        pct = 100.0 * n / max(1, self._count())
+        lows, highs = edges[:-1], edges[1:]
+        labels = [f"[{lo:.2f}, {hi:.2f})" if i < len(lows) - 1 else f"[{lo:.2f}, {hi:.2f}]" for i, (lo, hi) in enumerate(zip(lows, highs))]
+        return pd.DataFrame({"low": lows, "high": highs, "label": labels, "n": n, "pct": pct, "accuracy": acc})
+
+    def plot_accuracy_vs_uncertainty_bins(self, num_bins: int = 10, bin_width=None, bin_edges=None, figsize=(14, 5),
+                                          title="Pixel Accuracy vs Predictive-Uncertainty (binned)", x_label="Normalized predictive-entropy bin",
+                                          y_label="Accuracy", show_percent_on_bars: bool = True, annotate_min_pct: float = 0.1,
+                                          annotate_every: int = 1, percent_fmt: str = "{:.1f}%", save_path=None, show: bool = False,
+                                          close_fig: bool = True, dpi: int = 200, cmap_name: str = "viridis", color_norm: str = "linear"):
+        """Bar chart of the binned accuracy coloured by the share of points per bin; returns (fig, ax) like the reference (a plain
+        rendering: bars, overall-accuracy line, percentage labels, colour bar)."""
+        stats = self.binned_accuracy(num_bins=num_bins, bin_width=bin_width, bin_edges=bin_edges)
+        if stats.empty or stats["n"].sum() == 0:
+            print("No data to plot.")
+            return
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        from matplotlib.cm import ScalarMappable
+        from matplotlib.colors import LogNorm, Normalize
+        pct = stats["pct"].to_numpy()
+        if color_norm == "log":
+            vmin = max(1e-3, float(pct[pct > 0].min()) if (pct > 0).any() else 1e-3)
+            norm = LogNorm(vmin=vmin, vmax=max(vmin * 10, float(pct.max() or 1.0)))
+        else:
+            norm = Normalize(vmin=0.0, vmax=100.0 if color_norm == "linear" else max(1.0, float(pct.max())))
+        cmap = matplotlib.colormaps[cmap_name]
+        colors = cmap(norm(pct))
+        colors[stats["n"].to_numpy() == 0, 3] = 0.25
+        fig, ax = plt.subplots(figsize=figsize, dpi=dpi)
+        bars = ax.bar(stats["label"].to_list(), np.nan_to_num(stats["accuracy"].to_numpy(), nan=0.0), color=colors, edgecolor="black", linewidth=0.8)
+        ax.set_ylim(0.0, 1.0)
+        ax.set_title(title, fontsize=18, weight="bold", pad=10)
+        ax.set_xlabel(x_label, fontsize=12)
+        ax.set_ylabel(y_label, fontsize=12)
+        ax.tick_params(axis="x", rotation=45)
+        overall = float(self._correct.float().mean()) if self._count() else float("nan")
+        if np.isfinite(overall):
+            ax.axhline(overall, ls="--", lw=2, color="black", alpha=0.85)
+            ax.text(len(stats) - 0.5, overall + 0.012, f"overall = {overall:.3f}", ha="right", va="bottom", fontsize=12, fontweight="bold")
+        if show_percent_on_bars:
+            for i, (bar, pct_i, n_i) in enumerate(zip(bars, stats["pct"].to_list(), stats["n"].to_list())):
+                if n_i == 0:
+                    continue
+                small = pct_i < float(annotate_min_pct) or i % max(1, int(annotate_every)) != 0
+                ax.text(bar.get_x() + bar.get_width() / 2.0, 0.015, f"<{float(annotate_min_pct):.1f}%" if small else percent_fmt.format(pct_i),
+                        ha="center", va="bottom", fontsize=9)
+        sm = ScalarMappable(norm=norm, cmap=cmap)
+        sm.set_array([])
+        fig.colorbar(sm, ax=ax, pad=0.01).set_label("Percentage of points (%)", rotation=90)
+        fig.tight_layout()
+        if save_path is not None:
+            fig.savefig(save_path, dpi=dpi, bbox_inches="tight")
+        return fig, ax

@@ -695,3 +695,37 @@ def auroc_from_samples(scores: torch.Tensor, is_error: torch.Tensor, want_sorted
           "slu_auroc_compute")
     a, p, nn_ = (float(v) for v in out.cpu())
     return (a, int(p), int(nn_), ss, se) if want_sorted else (a, int(p), int(nn_))
+
+
+# ------------------------------------------------------------------------------------------------
+# accuracy vs uncertainty bins (models/evaluator.py UncertaintyAccuracyAggregator)
+# ------------------------------------------------------------------------------------------------
+def ua_samples(labels: torch.Tensor, preds: torch.Tensor, uncertainty: torch.Tensor, ignore_ids=()):
+    """(u fp32 [n] clamped to [0,1], flag uint8 [n]: 1 correct / 0 wrong / 2 label in ignore_ids), flattened scan order."""
+    _req(labels, "labels", torch.int64)
+    _req(preds, "preds", torch.int64)
+    _req(uncertainty, "uncertainty")
+    if not (labels.shape == preds.shape == uncertainty.shape) or labels.numel() == 0:
+        raise RuntimeError("ua_samples: labels, preds and uncertainty must have the same non-empty shape")
+    n = labels.numel()
+    ids = torch.tensor(list(ignore_ids), dtype=torch.int64, device=labels.device) if len(ignore_ids) else None
+    u = torch.empty(n, dtype=torch.float32, device=labels.device)
+    f = torch.empty(n, dtype=torch.uint8, device=labels.device)
+    check(_lib.load().slu_ua_samples(labels.data_ptr(), preds.data_ptr(), uncertainty.data_ptr(), n, _ptr(ids), 0 if ids is None else ids.numel(),
+                                     u.data_ptr(), f.data_ptr(), _stream()), "slu_ua_samples")
+    return u, f
+
+
+def binned_counts(u: torch.Tensor, correct: torch.Tensor, edges: torch.Tensor):
+    """np.histogram(u, bins=edges) and the histogram of the correct ones, on the device: (count int64 [K], n_correct int64 [K])."""
+    _req(u, "u")
+    _req(correct, "correct", torch.uint8)
+    _req(edges, "edges")
+    if u.dim() != 1 or u.shape != correct.shape or u.numel() == 0 or edges.dim() != 1 or not 2 <= edges.numel() <= 257:
+        raise RuntimeError("binned_counts: 1-D samples and 2..257 edges expected")
+    k = edges.numel() - 1
+    cnt = torch.zeros(k, dtype=torch.int64, device=u.device)
+    ok = torch.zeros(k, dtype=torch.int64, device=u.device)
+    check(_lib.load().slu_binned_counts(u.data_ptr(), correct.data_ptr(), u.numel(), edges.data_ptr(), k, cnt.data_ptr(), ok.data_ptr(), _stream()),
+          "slu_binned_counts")
+    return cnt, ok

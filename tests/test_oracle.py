@@ -165,3 +165,23 @@ def test_auroc_golden_and_known_answers():
     assert ometrics.auroc_from_samples(np.array([0.9, 0.8, 0.2, 0.1]), np.array([0, 0, 1, 1])) == 0.0
     assert ometrics.auroc_from_samples(np.array([0.9, 0.2, 0.8, 0.1]), np.array([1, 1, 0, 0])) == 0.75
     assert np.isnan(ometrics.auroc_from_samples(np.array([0.3, 0.2]), np.array([1, 1])))
+
+
+def test_accuracy_vs_uncertainty_bins_golden():
+    """oracle.metrics.ua_* against the counts / accuracies the reference's UncertaintyAccuracyAggregator produced."""
+    g = golden("ua_bins_2x16x64")
+    lab, prd, unc = (torch.from_numpy(g[k]) for k in ("labels", "preds", "uncertainty"))
+    u1, c1 = ometrics.ua_samples(lab, prd, unc, (0, 7))
+    u2, c2 = ometrics.ua_samples(lab.flip(0), prd.flip(0), unc.flip(0))
+    u, c = np.concatenate([u1, u2]), np.concatenate([c1, c2])
+    assert float(u.min()) >= 0.0 and float(u.max()) <= 1.0
+    for tag, kw in (("bins10", {}), ("width0.05", {"bin_width": 0.05}), ("bins64", {"num_bins": 64}),
+                    ("custom", {"bin_edges": np.array([0.0, 0.05, 0.3, 0.31, 0.8, 1.0], dtype=np.float32)})):
+        edges = ometrics.ua_make_bins(kw.get("num_bins", 10), kw.get("bin_width"), kw.get("bin_edges"))
+        assert np.array_equal(edges, g["edges:" + tag])
+        n, acc, pct = ometrics.ua_binned(u, c, edges)
+        assert np.array_equal(n, g["n:" + tag]) and np.allclose(acc, g["accuracy:" + tag], equal_nan=True, rtol=0, atol=0)
+        assert abs(float(pct.sum()) - 100.0) < 1e-9
+    # known answers: values on an interior edge go right, the last bin is closed
+    n, acc, _ = ometrics.ua_binned(np.array([0.0, 0.5, 0.5, 1.0], np.float32), np.array([1, 0, 1, 1]), ometrics.ua_make_bins(2))
+    assert n.tolist() == [1, 3] and acc.tolist() == [1.0, 2.0 / 3.0]

@@ -288,6 +288,37 @@ def main():
     save("auroc_2x20x16x64", **out)
     print("  oracle.metrics.auroc_* == reference AUROCAggregator (samples and AUROC identical)")
 
+    # ---------------- accuracy vs uncertainty bins (models/evaluator.py UncertaintyAccuracyAggregator) ----------------
+    from models.evaluator import UncertaintyAccuracyAggregator as RefUA      # reference (seaborn / cv2 stubbed above)
+    g = torch.Generator().manual_seed(123)
+    ua_lab = torch.randint(0, 20, (2, 16, 64), generator=g)
+    ua_prd = torch.where(torch.rand(2, 16, 64, generator=g) < 0.7, ua_lab, torch.randint(0, 20, (2, 16, 64), generator=g))
+    ua_unc = torch.rand(2, 16, 64, generator=g) * 1.2 - 0.1                   # some values outside [0, 1]: clamped by update()
+    ua_unc[0, 0, :8] = torch.tensor([0.0, 0.1, 0.2, 0.3, 0.5, 0.9, 1.0, 1.0])  # values on bin edges
+    out = {"labels": ua_lab.numpy(), "preds": ua_prd.numpy(), "uncertainty": ua_unc.numpy()}
+    agg = RefUA()
+    agg.update(ua_lab, ua_prd, ua_unc, ignore_ids=(0, 7))
+    agg.update(ua_lab.flip(0), ua_prd.flip(0), ua_unc.flip(0))
+    u1, c1 = ometrics.ua_samples(ua_lab, ua_prd, ua_unc, (0, 7))
+    u2, c2 = ometrics.ua_samples(ua_lab.flip(0), ua_prd.flip(0), ua_unc.flip(0))
+    uo, co = np.concatenate([u1, u2]), np.concatenate([c1, c2])
+    assert np.array_equal(uo, agg._uncert.numpy()) and np.array_equal(co, agg._correct.numpy())
+    custom = np.array([0.0, 0.05, 0.3, 0.31, 0.8, 1.0], dtype=np.float32)
+    for tag, kw in (("bins10", {}), ("width0.05", {"bin_width": 0.05}), ("custom", {"bin_edges": custom}), ("bins64", {"num_bins": 64})):
+        df = agg.binned_accuracy(**kw)
+        edges = ometrics.ua_make_bins(kw.get("num_bins", 10), kw.get("bin_width"), kw.get("bin_edges"))
+        n_o, acc_o, pct_o = ometrics.ua_binned(uo, co, edges)
+        assert np.array_equal(df["n"].to_numpy(), n_o) and np.allclose(df["accuracy"].to_numpy(), acc_o, equal_nan=True, rtol=0, atol=0)
+        assert np.array_equal(df["low"].to_numpy(), edges[:-1]) and np.allclose(df["pct"].to_numpy(), pct_o, rtol=0, atol=0)
+        out["n:" + tag], out["accuracy:" + tag], out["edges:" + tag] = n_o, acc_o, edges
+    agg = RefUA(max_samples=900, seed=0)
+    for k in range(3):
+        agg.update(ua_lab.roll(k, 0), ua_prd.roll(k, 1), ua_unc.roll(k, 2), ignore_ids=(0,))
+    out["capped_n:bins10"] = agg.binned_accuracy()["n"].to_numpy()
+    out["capped_accuracy:bins10"] = agg.binned_accuracy()["accuracy"].to_numpy()
+    save("ua_bins_2x16x64", **out)
+    print("  oracle.metrics.ua_* == reference UncertaintyAccuracyAggregator (samples, counts, accuracies identical)")
+
     # ---------------- ResNet-FPN (models/semanticFCN.py) through a stub torchvision serving oracle.fpn.ResNetRef ----------------
     from oracle import fpn as ofpn
     from semanticlidarunc_amd.fpn import SemanticNetworkWithFPN as MyFPN
