@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 8
+#define SLU_ABI_VERSION 9
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -325,6 +325,17 @@ int slu_ua_samples(const int64_t* labels, const int64_t* preds, const float* unc
                    float* u_out, uint8_t* flags, slu_stream_t stream);
 int slu_binned_counts(const float* u, const uint8_t* correct, long long n, const float* edges, int n_bins, int64_t* count, int64_t* n_correct,
                       slu_stream_t stream);
+
+/* ---- Tversky loss (models/losses.py:74-128, the 'Tversky' loss branch trainer.py:497-503) -----------------------
+ * valid = 0 <= y < C and (no ignore or y != ignore_index); p by model_act (0 logits: softmax, 1 probs, 2 log_probs: exp);
+ * per class over valid pixels S = sum p, TP = sum p [y = c], N = #[y = c];  tversky = (TP + s) / (TP + alpha (S - TP) + beta (N - TP) + s);
+ * loss = mean (reduction 0) / sum (1) / per class (2) of 1 - tversky; 0 when no pixel is valid.
+ * fwd: sums double [3][C] (S | TP | N, zeroed inside), coef float [2][C] (backward coefficients), loss float [1] or [C], any_valid [1].
+ * bwd: grad_x [B,C,H,W] = d loss / d x through the activation; grad_out = upstream gradient (DEVICE, [1] or [C], NULL = 1). */
+int slu_tversky_fwd(const float* x, const int64_t* labels, int B, int C, int HW, int model_act, int has_ignore, int64_t ignore_index, float alpha,
+                    float beta, float smooth, int reduction, double* sums, float* coef, float* loss, float* any_valid, slu_stream_t stream);
+int slu_tversky_bwd(const float* x, const int64_t* labels, int B, int C, int HW, int model_act, int has_ignore, int64_t ignore_index, float alpha,
+                    float beta, const float* coef, const float* grad_out, int grad_out_per_class, float* grad_x, slu_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -72,3 +72,30 @@ def cross_entropy(outputs, labels, ignore_index=255, model_act="logits"):
     if model_act == "log_probs":
         return F.nll_loss(outputs, labels, ignore_index=ignore_index)
     raise ValueError(f"Unknown model_act: {model_act}")
+
+
+
+def tversky(outputs, labels, num_classes=20, model_act="logits", alpha=0.9, beta=0.1, smooth=1.0, ignore_index=255, reduction="mean"):
+    """models/losses.py:74-128: per-class Tversky index over the valid pixels (0 <= y < C, y != ignore), loss = reduce(1 - index)."""
+    if model_act == "logits":
+        probs = F.softmax(outputs, dim=1)
+    elif model_act == "probs":
+        probs = outputs
+    elif model_act == "log_probs":
+        probs = outputs.exp()
+    else:
+        raise ValueError(f"Unknown model_act: {model_act}")
+    labels = labels.long()
+    valid = (labels >= 0) & (labels < num_classes)
+    if ignore_index is not None:
+        valid = valid & (labels != ignore_index)
+    if not valid.any():
+        return probs.new_tensor(0.0, requires_grad=True)
+    one_hot = F.one_hot(torch.where(valid, labels, torch.zeros_like(labels)), num_classes=num_classes).permute(0, 3, 1, 2).float()
+    vm = valid.unsqueeze(1).float()
+    probs, one_hot = probs * vm, one_hot * vm
+    tp = (probs * one_hot).sum((0, 2, 3))
+    fp = ((1 - one_hot) * probs).sum((0, 2, 3))
+    fn = (one_hot * (1 - probs)).sum((0, 2, 3))
+    loss = 1 - (tp + smooth) / (tp + alpha * fp + beta * fn + smooth)
+    return loss.mean() if reduction == "mean" else (loss.sum() if reduction == "sum" else loss)

@@ -49,3 +49,41 @@ class CrossEntropyLoss(nn.Module):
             raise ValueError(f"Unknown model_act: {model_act}")
         from semanticlidarunc_amd.loss import NllFn
         return NllFn.apply(outputs, labels, kind, param, self.ignore_index)
+
+
+
+class _TverskyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, outputs, labels, model_act, ignore_index, alpha, beta, smooth, reduction, num_classes):
+        x = outputs.detach().float().contiguous()
+        lab = labels.detach().to(device=x.device, dtype=torch.int64).contiguous()
+        if x.shape[1] != num_classes:
+            raise RuntimeError(f"TverskyLoss: outputs have {x.shape[1]} channels, num_classes = {num_classes}")
+        loss, coef, _ = ops.tversky_fwd(x, lab, model_act, ignore_index, alpha, beta, smooth, reduction)
+        ctx.save_for_backward(x, lab, coef)
+        ctx.cfg = (model_act, ignore_index, alpha, beta)
+        return loss if reduction == "none" else loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lab, coef = ctx.saved_tensors
+        model_act, ignore_index, alpha, beta = ctx.cfg
+        gx = ops.tversky_bwd(x, lab, model_act, ignore_index, alpha, beta, coef, g.detach().float().contiguous().reshape(-1))
+        return gx, None, None, None, None, None, None, None, None
+
+
+class TverskyLoss(nn.Module):
+    """1 - (TP + s) / (TP + alpha FP + beta FN + s) per class over the valid pixels, reduced over ALL classes
+    (reference models/losses.py:74-128); forward and backward are one fused HIP pass each."""
+
+    def __init__(self, alpha=0.9, beta=0.1, smooth=1.0, ignore_index=255, reduction="mean"):
+        super().__init__()
+        self.alpha, self.beta, self.smooth = alpha, beta, smooth
+        self.ignore_index = ignore_index
+        self.reduction = reduction
+
+    def forward(self, outputs, labels, num_classes=20, model_act="logits"):
+        if model_act not in ops.TVERSKY_ACTS:
+            raise ValueError(f"Unknown model_act: {model_act}")
+        reduction = self.reduction if self.reduction in ("mean", "sum") else "none"      # the reference returns the per-class vector otherwise
+        return _TverskyFn.apply(outputs, labels, model_act, self.ignore_index, self.alpha, self.beta, self.smooth, reduction, int(num_classes))

@@ -729,3 +729,44 @@ def binned_counts(u: torch.Tensor, correct: torch.Tensor, edges: torch.Tensor):
     check(_lib.load().slu_binned_counts(u.data_ptr(), correct.data_ptr(), u.numel(), edges.data_ptr(), k, cnt.data_ptr(), ok.data_ptr(), _stream()),
           "slu_binned_counts")
     return cnt, ok
+
+
+# ------------------------------------------------------------------------------------------------
+# Tversky loss (models/losses.py TverskyLoss)
+# ------------------------------------------------------------------------------------------------
+TVERSKY_ACTS = {"logits": 0, "probs": 1, "log_probs": 2}
+TVERSKY_REDUCTIONS = {"mean": 0, "sum": 1, "none": 2}
+
+
+def tversky_fwd(x: torch.Tensor, labels: torch.Tensor, model_act: str, ignore_index, alpha: float, beta: float, smooth: float, reduction: str):
+    """-> (loss [1] or [C], coef [2,C] for the backward, any_valid [1]) -- slu_tversky_fwd."""
+    _req(x, "outputs")
+    _req(labels, "labels", torch.int64)
+    if x.dim() != 4 or tuple(labels.shape) != (x.shape[0], x.shape[2], x.shape[3]):
+        raise RuntimeError(f"tversky: outputs [B,C,H,W] / labels [B,H,W] expected, got {tuple(x.shape)} / {tuple(labels.shape)}")
+    b, c, h, w = x.shape
+    red = TVERSKY_REDUCTIONS[reduction]
+    sums = torch.empty(3 * c, dtype=torch.float64, device=x.device)
+    coef = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    loss = torch.empty(c if red == 2 else 1, dtype=torch.float32, device=x.device)
+    anyv = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_tversky_fwd(x.data_ptr(), labels.data_ptr(), b, c, h * w, TVERSKY_ACTS[model_act], 0 if ignore_index is None else 1,
+                                      0 if ignore_index is None else int(ignore_index), float(alpha), float(beta), float(smooth), red,
+                                      sums.data_ptr(), coef.data_ptr(), loss.data_ptr(), anyv.data_ptr(), _stream()), "slu_tversky_fwd")
+    return loss, coef, anyv
+
+
+def tversky_bwd(x: torch.Tensor, labels: torch.Tensor, model_act: str, ignore_index, alpha: float, beta: float, coef: torch.Tensor,
+                grad_out: torch.Tensor):
+    _req(x, "outputs")
+    _req(labels, "labels", torch.int64)
+    _req(coef, "coef")
+    _req(grad_out, "grad_out")
+    b, c, h, w = x.shape
+    if grad_out.numel() not in (1, c):
+        raise RuntimeError("tversky_bwd: grad_out must have 1 or C elements")
+    gx = torch.empty_like(x)
+    check(_lib.load().slu_tversky_bwd(x.data_ptr(), labels.data_ptr(), b, c, h * w, TVERSKY_ACTS[model_act], 0 if ignore_index is None else 1,
+                                      0 if ignore_index is None else int(ignore_index), float(alpha), float(beta), coef.data_ptr(),
+                                      grad_out.data_ptr(), 1 if (grad_out.numel() == c and c > 1) else 0, gx.data_ptr(), _stream()), "slu_tversky_bwd")
+    return gx

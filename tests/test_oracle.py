@@ -185,3 +185,19 @@ def test_accuracy_vs_uncertainty_bins_golden():
     # known answers: values on an interior edge go right, the last bin is closed
     n, acc, _ = ometrics.ua_binned(np.array([0.0, 0.5, 0.5, 1.0], np.float32), np.array([1, 0, 1, 1]), ometrics.ua_make_bins(2))
     assert n.tolist() == [1, 3] and acc.tolist() == [1.0, 2.0 / 3.0]
+
+
+def test_tversky_golden():
+    """oracle.losses.tversky against the reference's TverskyLoss values and gradients."""
+    g = golden("tversky_2x20x8x64")
+    lab, logits = torch.from_numpy(g["labels"]), torch.from_numpy(g["logits"])
+    inputs = {"logits": logits, "probs": logits.softmax(1), "log_probs": logits.log_softmax(1)}
+    wgt = torch.linspace(0.5, 1.5, 20)
+    for act, inp in inputs.items():
+        for red in ("mean", "sum", "none"):
+            x = inp.clone().requires_grad_(True)
+            lo = olosses.tversky(x, lab, 20, act, 0.7, 0.3, 1.0, 255, red)
+            ((lo * wgt).sum() if red == "none" else lo).backward()
+            assert float((lo.detach() - torch.from_numpy(g[f"loss:{act}|{red}"])).abs().max()) == 0.0
+            assert float((x.grad - torch.from_numpy(g[f"grad:{act}|{red}"])).abs().max()) == 0.0
+    assert float(olosses.tversky(logits, torch.full((2, 8, 64), 255), 20, "logits")) == float(g["loss:all_ignored"]) == 0.0

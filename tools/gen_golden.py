@@ -319,6 +319,31 @@ def main():
     save("ua_bins_2x16x64", **out)
     print("  oracle.metrics.ua_* == reference UncertaintyAccuracyAggregator (samples, counts, accuracies identical)")
 
+    # ---------------- Tversky loss (models/losses.py) ----------------
+    from models.losses import TverskyLoss as RefTversky                 # reference
+    g = torch.Generator().manual_seed(55)
+    tv_lab = torch.randint(0, 20, (2, 8, 64), generator=g)
+    tv_lab[torch.rand(2, 8, 64, generator=g) < 0.1] = 255               # ignored
+    tv_lab[0, 0, :3] = torch.tensor([-1, 20, 31])                       # out-of-range labels are invalid too
+    tv_lab[tv_lab == 5] = 6                                             # class 5 absent
+    tv_logits = torch.randn(2, 20, 8, 64, generator=g) * 2.0
+    out = {"labels": tv_lab.numpy(), "logits": tv_logits.numpy()}
+    for act, inp in (("logits", tv_logits), ("probs", tv_logits.softmax(1)), ("log_probs", tv_logits.log_softmax(1))):
+        for red in ("mean", "sum", "none"):
+            xr = inp.clone().requires_grad_(True)
+            lr = RefTversky(alpha=0.7, beta=0.3, smooth=1.0, ignore_index=255, reduction=red)(xr, tv_lab, 20, act)
+            wgt = torch.linspace(0.5, 1.5, 20)
+            (lr * wgt).sum().backward() if red == "none" else lr.backward()
+            xo = inp.clone().requires_grad_(True)
+            lo = olosses.tversky(xo, tv_lab, 20, act, 0.7, 0.3, 1.0, 255, red)
+            (lo * wgt).sum().backward() if red == "none" else lo.backward()
+            assert maxdiff(lr.detach(), lo.detach()) == 0.0 and maxdiff(xr.grad, xo.grad) == 0.0, (act, red)
+            out[f"loss:{act}|{red}"] = lr.detach().numpy()
+            out[f"grad:{act}|{red}"] = xr.grad.numpy()
+    out["loss:all_ignored"] = RefTversky()(tv_logits, torch.full((2, 8, 64), 255), 20, "logits").detach().numpy()
+    save("tversky_2x20x8x64", **out)
+    print("  oracle.losses.tversky == reference TverskyLoss (value and gradient identical)")
+
     # ---------------- ResNet-FPN (models/semanticFCN.py) through a stub torchvision serving oracle.fpn.ResNetRef ----------------
     from oracle import fpn as ofpn
     from semanticlidarunc_amd.fpn import SemanticNetworkWithFPN as MyFPN
