@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 9
+#define SLU_ABI_VERSION 10
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -336,6 +336,18 @@ int slu_tversky_fwd(const float* x, const int64_t* labels, int B, int C, int HW,
                     float beta, float smooth, int reduction, double* sums, float* coef, float* loss, float* any_valid, slu_stream_t stream);
 int slu_tversky_bwd(const float* x, const int64_t* labels, int B, int C, int HW, int model_act, int has_ignore, int64_t ignore_index, float alpha,
                     float beta, const float* coef, const float* grad_out, int grad_out_per_class, float* grad_x, slu_stream_t stream);
+
+/* ---- per-pixel Dirichlet losses (losses/dirichlet_losses.py:73-221,317-385, losses/regularizers.py:291-389) -----
+ * loss = sum over valid pixels (label != ignore_index, 0 <= label < C) of v(alpha[:, pixel], label) / #valid, with
+ *   kind 0 NLLDirichletCategorical: -(log(a_y + eps) - log(a0 + eps))          kind 1 DigammaDirichletCE: psi(a0) - psi(a_y)
+ *   kind 2 BrierDirichlet: sum_i E[p_i^2] - 2 p_y + 1 (param = s_ref, < 0: alpha0)   kind 3 DirichletMSELoss (Sensoy eq. 5)
+ *   kind 4 KL_offClasses_to_uniform (with_conf_weighting = False): KL(Dir(alpha~) || Dir(1)), true class replaced by 1.
+ * fwd: sum (double[1]) and count (int64[1]) are zeroed and accumulated; the caller divides (0 valid pixels: loss 0).
+ * bwd: grad_alpha [B,C,H,W] = gscale[0] * d v / d alpha at valid pixels, 0 elsewhere; gscale = upstream gradient / count (DEVICE). */
+int slu_dirichlet_loss_fwd(const float* alpha, const int64_t* labels, int B, int C, int HW, int kind, float param, float eps, int has_ignore,
+                           int64_t ignore_index, double* sum, int64_t* count, slu_stream_t stream);
+int slu_dirichlet_loss_bwd(const float* alpha, const int64_t* labels, int B, int C, int HW, int kind, float param, float eps, int has_ignore,
+                           int64_t ignore_index, const float* gscale, float* grad_alpha, slu_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -46,3 +46,47 @@ def head(outputs, num_classes: int, t: float = T, eps: float = EPS):
     alpha = alpha_from_shape_and_scale(outputs[:, :num_classes], outputs[:, num_classes:num_classes + 1], t, eps)
     p_hat = alpha / (alpha.sum(dim=1, keepdim=True) + eps)
     return alpha, p_hat, predictive_entropy_norm(alpha, eps), alpha.argmax(dim=1)
+
+
+# ---- per-pixel Dirichlet losses (src/losses/dirichlet_losses.py:73-221,317-385; src/losses/regularizers.py:291-389) -----------
+def _masked_mean(per_pix, target, ignore_index):
+    valid = torch.ones_like(target, dtype=torch.bool) if ignore_index is None else target != ignore_index
+    w = valid.float()
+    return (per_pix * w).sum() / w.sum().clamp_min(1.0)
+
+
+def loss_nll_dircat(alpha, target, ignore_index=None, eps=1e-12):
+    a0, ay = alpha.sum(dim=1), alpha.gather(1, target.unsqueeze(1)).squeeze(1)
+    return _masked_mean(-(torch.log(ay + eps) - torch.log(a0 + eps)), target, ignore_index)
+
+
+def loss_digamma_ce(alpha, target, ignore_index=None):
+    a0, ay = alpha.sum(dim=1), alpha.gather(1, target.unsqueeze(1)).squeeze(1)
+    return _masked_mean(torch.digamma(a0) - torch.digamma(ay), target, ignore_index)
+
+
+def loss_brier(alpha, target, ignore_index=None, s_ref=None, eps=1e-12):
+    a0 = alpha.sum(dim=1, keepdim=True)
+    p = alpha / (a0 + eps)
+    sum_p2 = (p * p).sum(dim=1, keepdim=True)
+    s = a0 if s_ref is None else torch.as_tensor(float(s_ref), dtype=alpha.dtype)
+    per = ((s * sum_p2 + 1.0) / (s + 1.0) - 2.0 * p.gather(1, target.unsqueeze(1)) + 1.0).squeeze(1)
+    return _masked_mean(per, target, ignore_index)
+
+
+def loss_mse(alpha, target, ignore_index=None, eps=1e-8):
+    a0 = alpha.sum(dim=1, keepdim=True)
+    p = alpha / (a0 + eps)
+    y = torch.zeros_like(alpha).scatter_(1, target.unsqueeze(1), 1.0)
+    var = alpha * (a0 - alpha) / ((a0 * a0 + eps) * (a0 + 1.0))
+    return _masked_mean(((y - p) ** 2 + var).sum(dim=1), target, ignore_index)
+
+
+def loss_kl_off_uniform(alpha, target, ignore_index=None, eps=1e-8):
+    valid = torch.ones_like(target, dtype=torch.bool) if ignore_index is None else target != ignore_index
+    y = torch.zeros_like(alpha).scatter_(1, target.unsqueeze(1), 1.0)
+    at = (y + (1.0 - y) * alpha).permute(0, 2, 3, 1).reshape(-1, alpha.shape[1])[valid.reshape(-1)]
+    a = at.clamp_min(eps)
+    s = a.sum(dim=1, keepdim=True)
+    kl = torch.lgamma(s) - torch.lgamma(a).sum(dim=1, keepdim=True) + ((a - 1.0) * (torch.digamma(a) - torch.digamma(s))).sum(dim=1, keepdim=True)
+    return kl.squeeze(1).mean()

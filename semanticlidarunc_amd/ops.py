@@ -770,3 +770,38 @@ def tversky_bwd(x: torch.Tensor, labels: torch.Tensor, model_act: str, ignore_in
                                       0 if ignore_index is None else int(ignore_index), float(alpha), float(beta), coef.data_ptr(),
                                       grad_out.data_ptr(), 1 if (grad_out.numel() == c and c > 1) else 0, gx.data_ptr(), _stream()), "slu_tversky_bwd")
     return gx
+
+
+# ------------------------------------------------------------------------------------------------
+# per-pixel Dirichlet losses (losses/dirichlet_losses.py, losses/regularizers.py)
+# ------------------------------------------------------------------------------------------------
+DIRICHLET_LOSS_KINDS = {"nll_dircat": 0, "digamma_ce": 1, "brier": 2, "mse": 3, "kl_off_uniform": 4}
+
+
+def _dirichlet_loss_args(alpha, labels):
+    _req(alpha, "alpha")
+    _req(labels, "labels", torch.int64)
+    if alpha.dim() != 4 or tuple(labels.shape) != (alpha.shape[0], alpha.shape[2], alpha.shape[3]):
+        raise RuntimeError(f"dirichlet loss: alpha [B,C,H,W] / labels [B,H,W] expected, got {tuple(alpha.shape)} / {tuple(labels.shape)}")
+    return alpha.shape
+
+
+def dirichlet_loss_fwd(alpha: torch.Tensor, labels: torch.Tensor, kind: str, param: float, eps: float, ignore_index):
+    """-> (sum float64 [1], count int64 [1]) over the valid pixels."""
+    b, c, h, w = _dirichlet_loss_args(alpha, labels)
+    s = torch.empty(1, dtype=torch.float64, device=alpha.device)
+    n = torch.empty(1, dtype=torch.int64, device=alpha.device)
+    check(_lib.load().slu_dirichlet_loss_fwd(alpha.data_ptr(), labels.data_ptr(), b, c, h * w, DIRICHLET_LOSS_KINDS[kind], float(param), float(eps),
+                                             0 if ignore_index is None else 1, 0 if ignore_index is None else int(ignore_index), s.data_ptr(),
+                                             n.data_ptr(), _stream()), "slu_dirichlet_loss_fwd")
+    return s, n
+
+
+def dirichlet_loss_bwd(alpha: torch.Tensor, labels: torch.Tensor, kind: str, param: float, eps: float, ignore_index, gscale: torch.Tensor):
+    b, c, h, w = _dirichlet_loss_args(alpha, labels)
+    _req(gscale, "gscale")
+    g = torch.empty_like(alpha)
+    check(_lib.load().slu_dirichlet_loss_bwd(alpha.data_ptr(), labels.data_ptr(), b, c, h * w, DIRICHLET_LOSS_KINDS[kind], float(param), float(eps),
+                                             0 if ignore_index is None else 1, 0 if ignore_index is None else int(ignore_index),
+                                             gscale.data_ptr(), g.data_ptr(), _stream()), "slu_dirichlet_loss_bwd")
+    return g

@@ -1,0 +1,67 @@
+"""GPU: fused per-pixel Dirichlet losses against the reference's golden values / gradients and the oracle at
+full size.  Bars: value 1e-5 relative; gradient 2e-5 of its scale (fp32 digamma / trigamma / lgamma series vs torch's)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import dirichlet as odir
+from semanticlidarunc_amd.losses import dirichlet_losses as dl
+from semanticlidarunc_amd.losses.regularizers import KL_offClasses_to_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _modules():
+    return {"nll_dircat": dl.NLLDirichletCategorical(ignore_index=0), "digamma_ce": dl.DigammaDirichletCE(ignore_index=0),
+            "brier": dl.BrierDirichlet(ignore_index=0), "brier_sref40": dl.BrierDirichlet(ignore_index=0, s_ref=40.0),
+            "mse": dl.DirichletMSELoss(ignore_index=0), "kl_off_uniform": KL_offClasses_to_uniform(ignore_index=0)}
+
+
+def test_against_reference_golden(cuda):
+    g = golden("dirichlet_losses_2x20x8x64")
+    lab, alpha = _t(g["labels"]).to(cuda), _t(g["alpha"])
+    for name, mod in _modules().items():
+        a = alpha.to(cuda).requires_grad_(True)
+        loss = mod(a, lab[:, None] if name == "mse" else lab)
+        loss.backward()
+        want_l, want_g = float(g["loss:" + name]), _t(g["grad:" + name])
+        assert abs(float(loss.detach()) - want_l) <= 1e-5 * max(1.0, abs(want_l)), (name, float(loss.detach()), want_l)
+        assert float((a.grad.cpu() - want_g).abs().max()) <= 2e-5 * float(want_g.abs().max()) + 1e-9, name
+    # nothing valid: zero loss, zero gradient
+    a = alpha.to(cuda).requires_grad_(True)
+    z = dl.DirichletMSELoss(ignore_index=0)(a, torch.zeros(2, 8, 64, dtype=torch.int64, device=cuda))
+    z.backward()
+    assert float(z.detach()) == 0.0 and float(a.grad.abs().max()) == 0.0
+    assert float(dl.DirichletMSELoss()(torch.ones(1, 2, 4, 4, device=cuda), torch.zeros(1, 4, 4, dtype=torch.int64, device=cuda))) == 0.0   # C <= 2
+    with pytest.raises(NotImplementedError):
+        KL_offClasses_to_uniform(with_conf_weighting=True)
+    with pytest.raises(NotImplementedError):
+        dl.NLLDirichletCategorical(ignore_index=(0, 1))
+    with pytest.raises(RuntimeError):
+        dl.BrierDirichlet()(alpha, lab.cpu())                                   # CPU tensor: no fallback
+
+
+def test_full_size_against_oracle_and_reentrant_backward(cuda):
+    gen = torch.Generator().manual_seed(77)
+    lab = torch.randint(0, 20, (2, 64, 2048), generator=gen)
+    lab[torch.rand(2, 64, 2048, generator=gen) < 0.1] = 0
+    alpha = 1.0 + torch.nn.functional.softplus(torch.randn(2, 20, 64, 2048, generator=gen) * 2.0) * 10.0
+    ofn = {"nll_dircat": lambda a: odir.loss_nll_dircat(a, lab, 0), "digamma_ce": lambda a: odir.loss_digamma_ce(a, lab, 0),
+           "brier": lambda a: odir.loss_brier(a, lab, 0), "brier_sref40": lambda a: odir.loss_brier(a, lab, 0, 40.0),
+           "mse": lambda a: odir.loss_mse(a, lab, 0), "kl_off_uniform": lambda a: odir.loss_kl_off_uniform(a, lab, 0)}
+    for name, mod in _modules().items():
+        ao = alpha.clone().requires_grad_(True)
+        lo = ofn[name](ao)
+        lo.backward()
+        a = alpha.to(cuda).requires_grad_(True)
+        loss = mod(a, lab.to(cuda))
+        g1 = torch.autograd.grad(loss, a, retain_graph=True)[0]
+        g2 = torch.autograd.grad(loss, a, retain_graph=True)[0]
+        assert torch.equal(g1, g2)
+        assert abs(float(loss.detach()) - float(lo)) <= 1e-5 * max(1.0, abs(float(lo))), name
+        assert float((g1.cpu() - ao.grad).abs().max()) <= 3e-5 * float(ao.grad.abs().max()), name

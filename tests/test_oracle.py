@@ -201,3 +201,24 @@ def test_tversky_golden():
             assert float((lo.detach() - torch.from_numpy(g[f"loss:{act}|{red}"])).abs().max()) == 0.0
             assert float((x.grad - torch.from_numpy(g[f"grad:{act}|{red}"])).abs().max()) == 0.0
     assert float(olosses.tversky(logits, torch.full((2, 8, 64), 255), 20, "logits")) == float(g["loss:all_ignored"]) == 0.0
+
+
+def test_dirichlet_losses_golden():
+    """oracle.dirichlet.loss_* against the reference's Dirichlet loss modules (values and gradients)."""
+    from oracle import dirichlet as odir
+    g = golden("dirichlet_losses_2x20x8x64")
+    lab, alpha = torch.from_numpy(g["labels"]), torch.from_numpy(g["alpha"])
+    fns = {"nll_dircat": lambda a: odir.loss_nll_dircat(a, lab, 0), "digamma_ce": lambda a: odir.loss_digamma_ce(a, lab, 0),
+           "brier": lambda a: odir.loss_brier(a, lab, 0), "brier_sref40": lambda a: odir.loss_brier(a, lab, 0, 40.0),
+           "mse": lambda a: odir.loss_mse(a, lab, 0), "kl_off_uniform": lambda a: odir.loss_kl_off_uniform(a, lab, 0)}
+    for name, fn in fns.items():
+        a = alpha.clone().requires_grad_(True)
+        lo = fn(a)
+        lo.backward()
+        assert float((lo.detach() - torch.from_numpy(g["loss:" + name])).abs()) == 0.0
+        assert float((a.grad - torch.from_numpy(g["grad:" + name])).abs().max()) == 0.0
+    # known answers at the uniform prior alpha = 1 (C = 4): NLL = ln 4; digamma-CE = psi(4) - psi(1) = 1 + 1/2 + 1/3
+    one = torch.ones(1, 4, 1, 2)
+    y = torch.tensor([[[1, 3]]])
+    assert abs(float(odir.loss_nll_dircat(one, y)) - math.log(4.0)) < 1e-6
+    assert abs(float(odir.loss_digamma_ce(one, y)) - (1.0 + 0.5 + 1.0 / 3.0)) < 1e-6

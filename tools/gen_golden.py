@@ -344,6 +344,32 @@ def main():
     save("tversky_2x20x8x64", **out)
     print("  oracle.losses.tversky == reference TverskyLoss (value and gradient identical)")
 
+    # ---------------- per-pixel Dirichlet losses (losses/dirichlet_losses.py, losses/regularizers.py) ----------------
+    from losses import dirichlet_losses as ref_dl, regularizers as ref_reg     # reference
+    from oracle import dirichlet as odir2
+    g = torch.Generator().manual_seed(808)
+    dl_lab = torch.randint(0, 20, (2, 8, 64), generator=g)
+    dl_lab[torch.rand(2, 8, 64, generator=g) < 0.12] = 0                       # ignored
+    dl_alpha = 1.0 + torch.nn.functional.softplus(torch.randn(2, 20, 8, 64, generator=g) * 2.0) * torch.rand(2, 1, 8, 64, generator=g) * 30
+    out = {"labels": dl_lab.numpy(), "alpha": dl_alpha.numpy()}
+    pairs = [("nll_dircat", ref_dl.NLLDirichletCategorical(ignore_index=0), lambda a: odir2.loss_nll_dircat(a, dl_lab, 0)),
+             ("digamma_ce", ref_dl.DigammaDirichletCE(ignore_index=0), lambda a: odir2.loss_digamma_ce(a, dl_lab, 0)),
+             ("brier", ref_dl.BrierDirichlet(ignore_index=0), lambda a: odir2.loss_brier(a, dl_lab, 0)),
+             ("brier_sref40", ref_dl.BrierDirichlet(ignore_index=0, s_ref=40.0), lambda a: odir2.loss_brier(a, dl_lab, 0, 40.0)),
+             ("mse", ref_dl.DirichletMSELoss(ignore_index=0), lambda a: odir2.loss_mse(a, dl_lab, 0)),
+             ("kl_off_uniform", ref_reg.KL_offClasses_to_uniform(ignore_index=0), lambda a: odir2.loss_kl_off_uniform(a, dl_lab, 0))]
+    for name, ref_mod, ofn in pairs:
+        ar = dl_alpha.clone().requires_grad_(True)
+        lr = ref_mod(ar, dl_lab[:, None] if name == "mse" else dl_lab)          # [B,1,H,W] labels are accepted too
+        lr.backward()
+        ao = dl_alpha.clone().requires_grad_(True)
+        lo = ofn(ao)
+        lo.backward()
+        assert maxdiff(lr.detach(), lo.detach()) == 0.0 and maxdiff(ar.grad, ao.grad) == 0.0, name
+        out["loss:" + name], out["grad:" + name] = lr.detach().numpy(), ar.grad.numpy()
+    save("dirichlet_losses_2x20x8x64", **out)
+    print("  oracle.dirichlet.loss_* == reference Dirichlet losses (value and gradient identical)")
+
     # ---------------- ResNet-FPN (models/semanticFCN.py) through a stub torchvision serving oracle.fpn.ResNetRef ----------------
     from oracle import fpn as ofpn
     from semanticlidarunc_amd.fpn import SemanticNetworkWithFPN as MyFPN
