@@ -9,7 +9,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .. import ops
+from semanticlidarunc_amd import ops
 
 
 class AUROCAggregator:
@@ -94,3 +94,9 @@ class AUROCAggregator:
             ax.grid(True, alpha=0.3)
             fig.tight_layout(); fig.savefig(save_plot_path, bbox_inches="tight", dpi=dpi); plt.close(fig)
         return auroc, {"fpr": fpr, "tpr": tpr, "thresholds": thr}, fig
+
+
+# drop-in mode (this file shadows the reference's module of the same import path): names it does not define come from there
+from semanticlidarunc_amd._shadow import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(__name__, __file__, globals())

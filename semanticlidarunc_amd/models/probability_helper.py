@@ -9,9 +9,9 @@ from typing import Optional
 
 import torch
 
-from .. import _lib
-from .._lib import check
-from ..ops import _ptr, _req, _stream
+from semanticlidarunc_amd import _lib
+from semanticlidarunc_amd._lib import check
+from semanticlidarunc_amd.ops import _ptr, _req, _stream
 
 _EPS: float = 1e-8
 _T: float = 1.0
@@ -153,3 +153,9 @@ def dirichlet_head(outputs: torch.Tensor, num_classes: int, T: Optional[float] =
                                                get_alpha_temperature() if T is None else T, get_eps_value() if eps is None else eps,
                                                True, True, True, False, True)
     return alpha, p_hat, ent / math.log(num_classes), preds
+
+
+# drop-in mode (this file shadows the reference's module of the same import path): names it does not define come from there
+from semanticlidarunc_amd._shadow import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(__name__, __file__, globals())
