@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 10
+#define SLU_ABI_VERSION 11
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -348,6 +348,15 @@ int slu_dirichlet_loss_fwd(const float* alpha, const int64_t* labels, int B, int
                            int64_t ignore_index, double* sum, int64_t* count, slu_stream_t stream);
 int slu_dirichlet_loss_bwd(const float* alpha, const int64_t* labels, int B, int C, int HW, int kind, float param, float eps, int has_ignore,
                            int64_t ignore_index, const float* gscale, float* grad_alpha, slu_stream_t stream);
+
+/* ---- spherical projection of a point cloud into the range image (dataset/utils.py:61-67,288-349) ------------------
+ * pc: float64 [N][C] (x, y, z, then any channels: intensity, label ...; the reference's dataloader concatenates to float64,
+ * dataloader_semantic_KITTI.py:49).  Rows / columns by numpy.digitize on the reversed linspace bins (theta range = data min / max
+ * when use_data_theta_range, else [theta_min, theta_max]; phi in [-pi, pi]); per pixel the NEAREST point survives (the reference
+ * writes in descending range order); img float32 [H][W][C], zeros where no point fell; theta_range_out double[2] or NULL. */
+size_t slu_spherical_projection_workspace_bytes(int N, int H, int W);
+int slu_spherical_projection(const double* pc, int N, int C, int H, int W, int use_data_theta_range, double theta_min, double theta_max,
+                             void* workspace, size_t workspace_bytes, float* img, double* theta_range_out, slu_stream_t stream);
 
 #ifdef __cplusplus
 }

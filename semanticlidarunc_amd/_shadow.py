@@ -1,5 +1,5 @@
 """Drop-in plumbing for the sub-packages that mirror the reference's import paths (``utils``, ``models``, ``metrics``,
-``losses``, ``baselines``).
+``losses``, ``baselines``, ``dataset``).
 
 INTEGRATION.md puts ``semanticlidarunc_amd/`` ahead of the reference's ``src/`` on ``sys.path`` so that e.g.
 ``from models.evaluator import IoUEvaluator`` resolves here.  Two things must then keep working:

@@ -1,0 +1,149 @@
+// Spherical projection of a LiDAR point cloud into the range image (src/dataset/utils.py:61-67,288-349).
+//   phi = atan2(y, x), theta = -atan2(sqrt(x^2 + y^2), z) + pi/2, r = sqrt(x^2 + y^2 + z^2)              (float64, as the reference)
+//   rows:  bins_h = linspace(theta_min, theta_max, H)[::-1],  idx_h = digitize(theta, bins_h) - 1  (-1 wraps to the last row)
+//   cols:  bins_w = linspace(-pi, pi, W)[::-1],               idx_w = digitize(phi, bins_w) - 1
+//   the reference writes the points in descending range order, so the NEAREST point of a pixel survives; here the winner is found
+//   with a 64-bit atomicMin on the range bits (second pass: smallest point index among equal ranges), then its channels are copied.
+// Three passes over N points (~1.2e5 per scan): latency-bound, microseconds; fp64 so that bin assignment matches numpy's.
+#include "slu_common.h"
+
+namespace {
+
+constexpr double kPi = 3.141592653589793238462643383279502884;
+
+// numpy.linspace(start, stop, n)[i]: arange(n) * step + start with step = (stop - start) / (n - 1); the last sample is `stop` exactly
+__device__ __forceinline__ double linspace_at(double start, double stop, int n, int i) {
+  if (n == 1) return start;
+  if (i == n - 1) return stop;
+  const double step = (stop - start) / (double)(n - 1);
+  return __dadd_rn(__dmul_rn((double)i, step), start);          // no fused multiply-add: numpy rounds twice
+}
+
+// numpy.digitize(v, bins) - 1 for the DECREASING bins  b[k] = linspace(lo, hi, n)[n - 1 - k]  (right = False):
+//   digitize = smallest i with v >= b[i] (n if none); a -1 result indexes the last row / column, as numpy's negative index does
+__device__ __forceinline__ int digitize_desc(double v, double lo, double hi, int n) {
+  int a = 0, b = n;                       // invariant: v < bins[k] for k < a, v >= bins[k] for k >= b
+  while (a < b) {
+    const int mid = (a + b) >> 1;
+    if (v >= linspace_at(lo, hi, n, n - 1 - mid)) b = mid; else a = mid + 1;
+  }
+  const int idx = a - 1;
+  return idx < 0 ? n - 1 : idx;
+}
+
+__device__ __forceinline__ void angles(const double* p, double& phi, double& theta, double& r) {
+  const double x = p[0], y = p[1], z = p[2];
+  const double xy = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+  r = sqrt(__dadd_rn(xy, __dmul_rn(z, z)));
+  phi = atan2(y, x);
+  theta = -atan2(sqrt(xy), z) + kPi / 2;
+}
+
+__device__ __forceinline__ unsigned long long orderable(double v) {         // monotone map double -> uint64
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(256) void theta_minmax_kernel(const double* __restrict__ pc, int N, int C, unsigned long long* __restrict__ mm) {
+  unsigned long long lo = ~0ull, hi = 0ull;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    double phi, theta, r;
+    angles(pc + (size_t)i * C, phi, theta, r);
+    const unsigned long long k = orderable(theta);
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+}
+
+__device__ __forceinline__ double from_orderable(unsigned long long k) {
+  const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+// pass 1: pixel of every point, nearest range per pixel
+__global__ __launch_bounds__(256) void project_kernel(const double* __restrict__ pc, int N, int C, int H, int W, int use_data_range, double tmin, double tmax,
+                                                      const unsigned long long* __restrict__ mm, int* __restrict__ pixel,
+                                                      unsigned long long* __restrict__ best_r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (use_data_range) { tmin = from_orderable(mm[0]); tmax = from_orderable(mm[1]); }
+  double phi, theta, r;
+  angles(pc + (size_t)i * C, phi, theta, r);
+  const int row = digitize_desc(theta, tmin, tmax, H), col = digitize_desc(phi, -kPi, kPi, W);
+  const int px = row * W + col;
+  pixel[i] = px;
+  atomicMin(&best_r[px], (unsigned long long)__double_as_longlong(r));      // r >= 0: the bit pattern is monotone
+}
+
+// pass 2: among the points at the nearest range of their pixel, the smallest index
+__global__ __launch_bounds__(256) void winner_kernel(const double* __restrict__ pc, int N, int C, const int* __restrict__ pixel,
+                                                     const unsigned long long* __restrict__ best_r, int* __restrict__ winner) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double phi, theta, r;
+  angles(pc + (size_t)i * C, phi, theta, r);
+  if ((unsigned long long)__double_as_longlong(r) == best_r[pixel[i]]) atomicMin(&winner[pixel[i]], i);
+}
+
+// pass 3: copy the winner's channels (float32 image, zeros where no point fell)
+__global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ pc, int C, int HW, const int* __restrict__ winner, float* __restrict__ img) {
+  const int px = blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= HW) return;
+  const int w = winner[px];
+  for (int c = 0; c < C; ++c) img[(size_t)px * C + c] = w == 0x7fffffff ? 0.0f : (float)pc[(size_t)w * C + c];
+}
+
+__global__ void theta_range_kernel(const unsigned long long* __restrict__ mm, int use_data_range, double tmin, double tmax, double* __restrict__ out) {
+  out[0] = use_data_range ? from_orderable(mm[0]) : tmin;
+  out[1] = use_data_range ? from_orderable(mm[1]) : tmax;
+}
+
+size_t carve_proj(char* base, int N, int HW, unsigned long long** mm, int** pixel, unsigned long long** best, int** winner) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+  char* m = take(2 * sizeof(unsigned long long));
+  char* px = take((size_t)N * sizeof(int));
+  char* b = take((size_t)HW * sizeof(unsigned long long));
+  char* w = take((size_t)HW * sizeof(int));
+  if (base) { *mm = (unsigned long long*)m; *pixel = (int*)px; *best = (unsigned long long*)b; *winner = (int*)w; }
+  return off;
+}
+
+}  // namespace
+
+extern "C" size_t slu_spherical_projection_workspace_bytes(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  return carve_proj(nullptr, N, H * W, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int slu_spherical_projection(const double* pc, int N, int C, int H, int W, int use_data_theta_range, double theta_min, double theta_max,
+                                        void* workspace, size_t workspace_bytes, float* img, double* theta_range_out, slu_stream_t stream) {
+  if (!pc || !workspace || !img || N <= 0 || C < 3 || H <= 0 || W <= 0 || (long long)H * W > 0x7ffffffe) return SLU_EINVAL;
+  unsigned long long *mm, *best;
+  int *pixel, *winner;
+  if (carve_proj((char*)workspace, N, H * W, &mm, &pixel, &best, &winner) > workspace_bytes) return SLU_EINVAL;
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return SLU_EINVAL;
+  hipStream_t st = slu_stream(stream);
+  const int HW = H * W;
+  // theta min -> all ones, theta max -> 0, nearest range -> all ones (above any finite range), winner -> INT_MAX (= "no point")
+  if (hipMemsetAsync(mm, 0xff, sizeof(unsigned long long), st) != hipSuccess || hipMemsetAsync(mm + 1, 0, sizeof(unsigned long long), st) != hipSuccess ||
+      hipMemsetAsync(best, 0xff, (size_t)HW * sizeof(unsigned long long), st) != hipSuccess)
+    return SLU_ELAUNCH;
+  const unsigned nbp = (unsigned)((N + 255) / 256), nbx = (unsigned)((HW + 255) / 256);
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(winner), 0x7fffffff, (size_t)HW, st) != hipSuccess) return SLU_ELAUNCH;
+  if (use_data_theta_range)
+    hipLaunchKernelGGL(theta_minmax_kernel, dim3(nbp > 256 ? 256 : nbp), dim3(256), 0, st, pc, N, C, mm);
+  hipLaunchKernelGGL(project_kernel, dim3(nbp), dim3(256), 0, st, pc, N, C, H, W, use_data_theta_range, theta_min, theta_max, mm, pixel, best);
+  hipLaunchKernelGGL(winner_kernel, dim3(nbp), dim3(256), 0, st, pc, N, C, pixel, best, winner);
+  hipLaunchKernelGGL(gather_kernel, dim3(nbx), dim3(256), 0, st, pc, C, HW, winner, img);
+  if (theta_range_out)
+    hipLaunchKernelGGL(theta_range_kernel, dim3(1), dim3(1), 0, st, mm, use_data_theta_range, theta_min, theta_max, theta_range_out);
+  SLU_CHECK_LAUNCH();
+}

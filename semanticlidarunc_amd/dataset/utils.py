@@ -1,0 +1,43 @@
+"""Drop-in for ``spherical_projection`` / ``to_deflection_coordinates`` of the reference's ``dataset/utils.py`` (:61-67, :288-349):
+same arguments and return tuple ``(pj_img, alpha, (theta_min, theta_max), (phi_min, phi_max))`` with numpy arrays, the
+projection itself (angles, bin search, nearest-point selection, gather) running in HIP kernels (``csrc/projection.hip``).
+Every other helper of the reference module (plots, normals, rotations) is re-exported from the shadowed file in drop-in mode."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from semanticlidarunc_amd import ops
+
+
+def to_deflection_coordinates(x, y, z):
+    p = np.sqrt(x ** 2 + y ** 2)
+    phi = np.arctan2(y, x)
+    theta = -np.arctan2(p, z) + np.pi / 2
+    return phi, theta
+
+
+def spherical_projection(pc, height=64, width=2048, theta_range=None, th=1.0, sort_largest_first=False, bins_h=None, max_range=None,
+                         device="cuda"):
+    """pc: [N, C] array or tensor (x, y, z, ...).  The nearest point of a pixel survives (the reference writes the points in
+    descending range order); `th` / `max_range` are accepted and unused, as in the reference."""
+    if sort_largest_first or bins_h is not None:
+        raise NotImplementedError("the HIP projection implements the default nearest-point order and linspace row bins")
+    t = pc if isinstance(pc, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pc))
+    if not t.is_cuda:
+        t = t.to(device)
+    img, tr = ops.spherical_projection(t.to(torch.float64).contiguous(), height, width, theta_range)
+    theta_min, theta_max = (float(v) for v in tr.cpu())
+    if theta_range is not None:
+        theta_min, theta_max = theta_range
+    phi_min, phi_max = -np.pi, np.pi
+    bins_h = np.linspace(theta_min, theta_max, height)[::-1]
+    bins_w = np.linspace(phi_min, phi_max, width)[::-1]
+    alpha = np.sqrt(np.square(np.stack(width * [bins_h], axis=-1)) + np.square(np.stack(height * [bins_w], axis=0)))
+    return img.cpu().numpy(), alpha, (theta_min, theta_max), (phi_min, phi_max)
+
+
+# drop-in mode (this file shadows the reference's module of the same import path): names it does not define come from there
+from semanticlidarunc_amd._shadow import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(__name__, __file__, globals())

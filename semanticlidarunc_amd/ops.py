@@ -805,3 +805,23 @@ def dirichlet_loss_bwd(alpha: torch.Tensor, labels: torch.Tensor, kind: str, par
                                              0 if ignore_index is None else 1, 0 if ignore_index is None else int(ignore_index),
                                              gscale.data_ptr(), g.data_ptr(), _stream()), "slu_dirichlet_loss_bwd")
     return g
+
+
+# ------------------------------------------------------------------------------------------------
+# spherical projection (dataset/utils.py of the reference)
+# ------------------------------------------------------------------------------------------------
+def spherical_projection(pc: torch.Tensor, height: int, width: int, theta_range=None):
+    """pc float64 [N, C >= 3] on the GPU -> (img fp32 [H, W, C], theta_range float64 [2] on the device); nearest point per pixel."""
+    _req(pc, "pc", torch.float64)
+    if pc.dim() != 2 or pc.shape[1] < 3 or pc.shape[0] == 0:
+        raise RuntimeError(f"pc: expected [N, C >= 3], got {tuple(pc.shape)}")
+    n, c = pc.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.slu_spherical_projection_workspace_bytes(n, int(height), int(width)), dtype=torch.uint8, device=pc.device)
+    img = torch.empty((int(height), int(width), c), dtype=torch.float32, device=pc.device)
+    tr = torch.empty(2, dtype=torch.float64, device=pc.device)
+    use_data = theta_range is None
+    tmin, tmax = (0.0, 0.0) if use_data else (float(theta_range[0]), float(theta_range[1]))
+    check(lib.slu_spherical_projection(pc.data_ptr(), n, c, int(height), int(width), 1 if use_data else 0, tmin, tmax, ws.data_ptr(), ws.numel(),
+                                       img.data_ptr(), tr.data_ptr(), _stream()), "slu_spherical_projection")
+    return img, tr

@@ -222,3 +222,18 @@ def test_dirichlet_losses_golden():
     y = torch.tensor([[[1, 3]]])
     assert abs(float(odir.loss_nll_dircat(one, y)) - math.log(4.0)) < 1e-6
     assert abs(float(odir.loss_digamma_ce(one, y)) - (1.0 + 0.5 + 1.0 / 3.0)) < 1e-6
+
+
+def test_spherical_projection_golden_and_known_answers():
+    """oracle.projection against the image the reference's dataset.utils.spherical_projection produced."""
+    from oracle import projection as oproj
+    g = golden("spherical_projection_30000x5_32x256")
+    for tag, tr in (("data_range", None), ("fixed_range", [-np.pi / 8, np.pi / 8])):
+        img, alpha, th, ph = oproj.spherical_projection(g["cloud"], 32, 256, theta_range=tr)
+        assert np.array_equal(img, g["img:" + tag]) and np.array_equal(np.asarray(th, dtype=np.float64), g["theta_range:" + tag])
+        assert alpha.shape == (32, 256) and ph == (-np.pi, np.pi)
+    # two points in one pixel: the nearer one survives; a point on the +x axis (phi = 0) lands in the middle column
+    pts = np.array([[10.0, 0.0, 0.0, 0.5, 3.0], [5.0, 0.0, 0.0, 0.9, 7.0], [0.0, -8.0, 1.0, 0.1, 2.0]])
+    img, _, _, _ = oproj.spherical_projection(pts, 4, 8, theta_range=[-0.5, 0.5])
+    assert np.count_nonzero(img[..., 0] != 0) + np.count_nonzero(img[..., 1] != 0) == 2
+    assert float(img[..., 3].max()) == np.float32(0.9) and 7.0 in img[..., 4] and 3.0 not in img[..., 4]

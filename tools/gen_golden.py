@@ -370,6 +370,24 @@ def main():
     save("dirichlet_losses_2x20x8x64", **out)
     print("  oracle.dirichlet.loss_* == reference Dirichlet losses (value and gradient identical)")
 
+    # ---------------- spherical projection (dataset/utils.py; cv2 / seaborn stubbed above, used by its plotting helpers only) ----------------
+    from dataset.utils import spherical_projection as ref_projection      # reference
+    from oracle import projection as oproj
+    rs = np.random.default_rng(2024)
+    npts = 30000
+    az, el = rs.uniform(-np.pi, np.pi, npts), rs.uniform(-0.43, 0.05, npts)          # a 64-beam-like vertical field of view
+    rng_m = rs.uniform(2.0, 80.0, npts)
+    xyz = np.stack([rng_m * np.cos(el) * np.cos(az), rng_m * np.cos(el) * np.sin(az), rng_m * np.sin(el)], 1).astype(np.float32)
+    cloud = np.concatenate([xyz, rs.uniform(0, 1, (npts, 1)).astype(np.float32), rs.integers(0, 20, (npts, 1))], axis=-1)   # float64, as the dataloader
+    out = {"cloud": cloud}
+    for tag, tr in (("data_range", None), ("fixed_range", [-np.pi / 8, np.pi / 8])):
+        img_r, alpha_r, th_r, ph_r = ref_projection(cloud, 32, 256, theta_range=tr)
+        img_o, alpha_o, th_o, ph_o = oproj.spherical_projection(cloud, 32, 256, theta_range=tr)
+        assert np.array_equal(img_r, img_o) and np.array_equal(alpha_r, alpha_o) and tuple(th_r) == tuple(th_o), tag
+        out["img:" + tag], out["theta_range:" + tag] = img_r, np.asarray(th_r, dtype=np.float64)
+    save("spherical_projection_30000x5_32x256", **out)
+    print("  oracle.projection.spherical_projection == reference dataset.utils.spherical_projection (bit-identical image)")
+
     # ---------------- ResNet-FPN (models/semanticFCN.py) through a stub torchvision serving oracle.fpn.ResNetRef ----------------
     from oracle import fpn as ofpn
     from semanticlidarunc_amd.fpn import SemanticNetworkWithFPN as MyFPN
