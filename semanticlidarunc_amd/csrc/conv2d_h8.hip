@@ -741,35 +741,50 @@ __global__ __launch_bounds__(256) void avgpool3s2_h8_kernel(const uint4* __restr
 }
 
 // y[n, c, 2h+i, 2w+j] = x[n, 4c+2i+j, h, w] * s_in[n, 4c+2i+j] * s_out[n, c]   (nn.PixelShuffle(2) + both Dropout2d multipliers)
-// x: h8 with Gi = 4 Go' blocks ... y: h8 with Go = ceil(Cin/32) blocks (Cin = 8 Gi stored channels -> Cin/4 output channels)
+// x: h8 with Gi blocks at HxW; y: h8 with Go = ceil(2 Gi / 8) blocks at 2Hx2W.  One thread takes the four input records (blocks
+// 4 go .. 4 go + 3) of one input pixel -- 32 stored channels = 8 output channels x 4 sub-pixels -- and writes the four complete
+// output records of the 2x2 output patch: 16-byte loads and stores only, consecutive threads = consecutive azimuth.
 __global__ __launch_bounds__(256) void pixel_shuffle_h8_kernel(const uint4* __restrict__ x, const float* __restrict__ s_in,
                                                                const float* __restrict__ s_out, uint4* __restrict__ y, int N, int Gi, int Go, int H,
                                                                int W) {
-  const int OH = 2 * H, OW = 2 * W;
-  const size_t total = (size_t)N * Go * OH * OW;
-  const _Float16* xs = reinterpret_cast<const _Float16*>(x);
+  const size_t total = (size_t)N * Go * H * W;
+  const size_t HWi = (size_t)H * W;
+  const int OW = 2 * W;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int ox = (int)(e % OW);
-    size_t r = e / OW;
-    const int oy = (int)(r % OH);
-    r /= OH;
-    const int g = (int)(r % Go);
+    const int w = (int)(e % W);
+    size_t r = e / W;
+    const int h = (int)(r % H);
+    r /= H;
+    const int go = (int)(r % Go);
     const size_t n = r / Go;
-    const int sub = ((oy & 1) << 1) | (ox & 1);
-    const size_t pin = (size_t)(oy >> 1) * W + (ox >> 1);
-    float v[8];
+    // v[sub][k]: output channel 8 go + k at sub-pixel sub = 2 i + j  <-  stored channel 32 go + 4 k + sub = block 4 go + (k >> 1), slot 4 (k & 1) + sub
+    float v[4][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int co = g * 8 + k;
-      const int ci = 4 * co + sub;                     // stored channel
-      const bool ok = ci < Gi * 8;
-      const size_t idx = ok ? (((n * Gi + (ci >> 3)) * (size_t)H * W + pin) * 8 + (ci & 7)) : 0;
-      float t = ok ? (float)xs[idx] : 0.0f;
-      if (ok && s_in) t *= s_in[n * Gi * 8 + ci];
-      if (ok && s_out) t *= s_out[n * (Gi * 2) + co];
-      v[k] = t;
+    for (int q = 0; q < 4; ++q) {
+      const int gi = 4 * go + q;
+      const bool ok = gi < Gi;
+      const half8 rec = __builtin_bit_cast(half8, ok ? x[(n * Gi + gi) * HWi + (size_t)h * W + w] : make_uint4(0u, 0u, 0u, 0u));
+#pragma unroll
+      for (int slot = 0; slot < 8; ++slot) {
+        float t = (float)rec[slot];
+        if (ok && s_in) t *= s_in[n * Gi * 8 + gi * 8 + slot];
+        v[slot & 3][2 * q + (slot >> 2)] = t;
+      }
     }
-    y[e] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    if (s_out) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int co = 8 * go + k;
+        const float so = co < 2 * Gi ? s_out[n * (Gi * 2) + co] : 0.0f;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) v[sub][k] *= so;
+      }
+    }
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const size_t o = ((n * Go + go) * (size_t)(2 * H) + (2 * h + (sub >> 1))) * OW + 2 * w + (sub & 1);
+      y[o] = make_uint4(pack2(v[sub][0], v[sub][1]), pack2(v[sub][2], v[sub][3]), pack2(v[sub][4], v[sub][5]), pack2(v[sub][6], v[sub][7]));
+    }
   }
 }
 
@@ -1050,7 +1065,7 @@ extern "C" int slu_pixel_shuffle_h8(const void* x, const float* scale_in, const 
                                     slu_stream_t stream) {
   if (!x || !y || N <= 0 || Gin <= 0 || H <= 0 || W <= 0 || (((uintptr_t)x | (uintptr_t)y) & 15)) return SLU_EINVAL;
   const int Go = (Gin * 2 + 7) / 8;                 // Cin/4 = 2 Gin output channels
-  const size_t total = (size_t)N * Go * 4 * H * W;
+  const size_t total = (size_t)N * Go * H * W;      // one thread per (input pixel, output block)
   hipLaunchKernelGGL(pixel_shuffle_h8_kernel, dim3(grid_for(total)), dim3(256), 0, slu_stream(stream), reinterpret_cast<const uint4*>(x), scale_in,
                      scale_out, reinterpret_cast<uint4*>(y), N, Gin, Go, H, W);
   SLU_CHECK_LAUNCH();
