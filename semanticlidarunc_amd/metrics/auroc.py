@@ -10,68 +10,51 @@ import numpy as np
 import torch
 
 from semanticlidarunc_amd import ops
+from semanticlidarunc_amd._reservoir import CappedColumns
 
 
 class AUROCAggregator:
     def __init__(self, mode="alpha", score="entropy_norm", ignore_index=None, max_samples=None, seed=0, eps=1e-12):
-        assert mode in {"alpha", "logits", "probs"}
-        assert score in {"entropy", "entropy_norm", "mi", "mi_norm", "1-maxprob"}
+        if mode not in ops.AUROC_MODES or score not in ops.AUROC_SCORES:
+            raise AssertionError(f"mode must be one of {sorted(ops.AUROC_MODES)}, score one of {sorted(ops.AUROC_SCORES)}")
         self.mode, self.score = mode, score
         self.ignore_index = ignore_index
         self.max_samples = max_samples
-        self.rng = np.random.default_rng(seed)
         self.eps = float(eps)
-        self.reset()
+        self._buf = CappedColumns(max_samples, seed)       # columns: score fp32, is_error uint8 (device)
+
+    # the reference's attribute names, for code that inspects the aggregator
+    @property
+    def rng(self):
+        return self._buf.rng
+
+    @property
+    def _scores(self):
+        return None if self._buf.columns is None else self._buf.columns[0]
+
+    @property
+    def _is_error(self):
+        return None if self._buf.columns is None else self._buf.columns[1]
+
+    @property
+    def _seen(self):
+        return self._buf.seen
 
     def reset(self):
-        self._scores = None      # 1-D fp32 device tensor
-        self._is_error = None    # 1-D uint8 device tensor
-        self._seen = 0
-
-    def _count(self) -> int:
-        return 0 if self._scores is None else self._scores.numel()
-
-    def _append(self, score, is_err):
-        self._scores = score if self._scores is None else torch.cat([self._scores, score])
-        self._is_error = is_err if self._is_error is None else torch.cat([self._is_error, is_err])
+        self._buf.clear()
 
     @torch.no_grad()
     def update(self, preds: torch.Tensor, labels: torch.Tensor, score_override: torch.Tensor | None = None):
-        assert preds.dim() == 4 and (labels.dim() == 3 or (labels.dim() == 4 and labels.size(1) == 1)), "labels must be [B,H,W] or [B,1,H,W]"
-        if labels.dim() == 4:
-            labels = labels[:, 0]
-        so = None if score_override is None else score_override.to(torch.float32).contiguous()
-        smap, flags = ops.auroc_scores(preds.contiguous().float(), labels.long().contiguous(), self.mode, self.score, self.ignore_index,
-                                       self.eps, so)
-        valid = flags != 2
-        score, is_err = smap[valid], flags[valid]            # NCHW scan order, as the reference's boolean-mask indexing
-        n_new = score.numel()
-        if n_new == 0:
-            return
-        if self.max_samples is None:
-            self._append(score, is_err)
-            self._seen += n_new
-            return
-        # reservoir-style cap (auroc.py:125-141): the same numpy draws, applied to the device buffers
-        self._seen += n_new
-        if self._count() < self.max_samples:
-            take = min(self.max_samples - self._count(), n_new)
-            if take < n_new:
-                idx = torch.from_numpy(self.rng.choice(n_new, size=take, replace=False)).to(score.device)
-                score, is_err = score[idx], is_err[idx]
-            self._append(score, is_err)
-        else:
-            p_keep = min(1.0, float(self.max_samples) / float(self._seen + 1e-9))
-            keep = torch.from_numpy(self.rng.random(n_new) < p_keep)
-            if keep.any():
-                keep = keep.to(score.device)
-                score, is_err = score[keep], is_err[keep]
-                replace_idx = torch.from_numpy(self.rng.choice(self.max_samples, size=score.numel(), replace=False)).to(score.device)
-                self._scores[replace_idx] = score
-                self._is_error[replace_idx] = is_err
+        if preds.dim() != 4 or not (labels.dim() == 3 or (labels.dim() == 4 and labels.size(1) == 1)):
+            raise AssertionError("labels must be [B,H,W] or [B,1,H,W]")
+        lab = (labels[:, 0] if labels.dim() == 4 else labels).long().contiguous()
+        override = None if score_override is None else score_override.to(torch.float32).contiguous()
+        score_map, flags = ops.auroc_scores(preds.contiguous().float(), lab, self.mode, self.score, self.ignore_index, self.eps, override)
+        keep = flags != 2                                    # boolean-mask order == the reference's NCHW scan order
+        self._buf.push(score_map[keep], flags[keep])
 
     def compute(self, save_plot_path: str | None = None, title: str = "ROC: error detection", dpi: int = 200):
-        if self._count() == 0:
+        if len(self._buf) == 0:
             return float("nan"), {}
         auroc, pos, neg, ss, se = ops.auroc_from_samples(self._scores.contiguous(), self._is_error.contiguous(), want_sorted=True)
         if np.isnan(auroc):
