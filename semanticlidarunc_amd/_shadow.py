@@ -27,29 +27,39 @@ def merge_package_path(path, name):
     return extend_path(path, name)
 
 
-def reexport_missing(module_name: str, module_file: str, namespace: dict) -> bool:
-    """Copy into ``namespace`` the names the shadowed reference module defines and the mirror does not.
-    Returns True if a shadowed file was found and loaded."""
+def shadowed_module(module_name: str, module_file: str):
+    """The reference module this mirror shadows (loaded once under a private name), or None."""
     if module_name.startswith("semanticlidarunc_amd."):
-        return False                                    # imported under the package's own name: nothing is shadowed
+        return None                                     # imported under the package's own name: nothing is shadowed
+    private = "_slu_shadowed_." + module_name
+    if private in sys.modules:
+        return sys.modules[private]
     rel = os.path.join(*module_name.split(".")) + ".py"
     here = os.path.realpath(module_file)
     for entry in sys.path:
         cand = os.path.join(entry or ".", rel)
         if os.path.isfile(cand) and os.path.realpath(cand) != here:
-            private = "_slu_shadowed_." + module_name
             try:
                 spec = importlib.util.spec_from_file_location(private, cand)
                 mod = importlib.util.module_from_spec(spec)
                 sys.modules[private] = mod
                 spec.loader.exec_module(mod)
+                return mod
             except Exception as exc:                    # the reference module needs something this environment lacks
                 sys.modules.pop(private, None)
                 warnings.warn(f"{module_name}: could not load the shadowed reference module {cand} ({exc!r}); "
                               "names this mirror does not define stay undefined")
-                return False
-            for key, value in vars(mod).items():
-                if key not in namespace and not (key.startswith("__") and key.endswith("__")):
-                    namespace[key] = value
-            return True
-    return False
+                return None
+    return None
+
+
+def reexport_missing(module_name: str, module_file: str, namespace: dict) -> bool:
+    """Copy into ``namespace`` the names the shadowed reference module defines and the mirror does not.
+    Returns True if a shadowed file was found and loaded."""
+    mod = shadowed_module(module_name, module_file)
+    if mod is None:
+        return False
+    for key, value in vars(mod).items():
+        if key not in namespace and not (key.startswith("__") and key.endswith("__")):
+            namespace[key] = value
+    return True

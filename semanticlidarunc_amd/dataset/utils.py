@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import numpy as np
 import torch
+import torch.utils.data
 
 from semanticlidarunc_amd import ops
 
@@ -21,6 +22,12 @@ def spherical_projection(pc, height=64, width=2048, theta_range=None, th=1.0, so
                          device="cuda"):
     """pc: [N, C] array or tensor (x, y, z, ...).  The nearest point of a pixel survives (the reference writes the points in
     descending range order); `th` / `max_range` are accepted and unused, as in the reference."""
+    if torch.utils.data.get_worker_info() is not None:
+        # a forked DataLoader worker must not touch the GPU: hand the call to the module this file shadows (the reference's numpy code)
+        if _shadowed is not None:
+            return _shadowed.spherical_projection(pc, height, width, theta_range, th, sort_largest_first, bins_h, max_range)
+        raise RuntimeError("spherical_projection: the HIP projection cannot run inside a DataLoader worker process; "
+                           "project in the main process (num_workers=0) or keep the reference's dataset/utils.py on sys.path")
     if sort_largest_first or bins_h is not None:
         raise NotImplementedError("the HIP projection implements the default nearest-point order and linspace row bins")
     t = pc if isinstance(pc, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pc))
@@ -38,6 +45,7 @@ def spherical_projection(pc, height=64, width=2048, theta_range=None, th=1.0, so
 
 
 # drop-in mode (this file shadows the reference's module of the same import path): names it does not define come from there
-from semanticlidarunc_amd._shadow import reexport_missing as _reexport_missing  # noqa: E402
+from semanticlidarunc_amd._shadow import reexport_missing as _reexport_missing, shadowed_module as _shadowed_module  # noqa: E402
 
+_shadowed = _shadowed_module(__name__, __file__)
 _reexport_missing(__name__, __file__, globals())

@@ -24,6 +24,8 @@ def test_shadowing_merges_packages_and_reexports_missing_names(tmp_path):
             return 'shadowed: must NOT win over the mirror'
     """))
     (src / "losses" / "dirichlet_losses.py").write_text("def _valid_mask(t, i):\n    return 'reference _valid_mask'\n")
+    (src / "dataset").mkdir()
+    (src / "dataset" / "utils.py").write_text("def spherical_projection(pc, *a, **k):\n    return 'reference numpy projection'\ndef rotate_z(p, a):\n    return 'ref rotate'\n")
     (src / "models" / "trainer_like.py").write_text(textwrap.dedent("""
         from models.evaluator import IoUEvaluator, UncertaintyAccuracyAggregator
         from models.probability_helper import to_alpha_concentrations_from_shape_and_scale, build_uncertainty_layers, get_eps_value
@@ -39,6 +41,11 @@ def test_shadowing_merges_packages_and_reexports_missing_names(tmp_path):
         assert t.get_eps_value() == 1e-8                      # the mirror's own definition wins
         assert t.only_in_reference().startswith('utils.vis_other')
         assert t.DirichletMSELoss.__module__ == 'losses.dirichlet_losses'
+        # the projection mirror: re-exports the other helpers, and inside a DataLoader worker hands the call to the shadowed module
+        import dataset.utils as du, torch.utils.data as tud
+        assert 'semanticlidarunc_amd' in du.__file__ and du.rotate_z(0, 0) == 'ref rotate'
+        tud.get_worker_info = lambda: object()
+        assert du.spherical_projection(None) == 'reference numpy projection'
         print('ok')
     """)
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "semanticlidarunc_amd"), str(src)]))
