@@ -40,6 +40,7 @@ struct H8Args {
   float slope;
   int out_f32;         // 1: `out` is fp32 NCHW [N][Cout][H][W] (the logits head); 0: h8
   int tiles_x, tiles_y;
+  int order;                 // 0: each workgroup walks a contiguous run of tiles; 1: tiles interleaved across workgroups
 };
 
 struct SrcSel {
@@ -150,6 +151,19 @@ __device__ __forceinline__ void store_tile_full(const H8Args& a, const f32x16& a
   }
 }
 
+#ifdef SLU_H8_PROF      // development aid: per-phase shader-clock totals of wave 0 of every workgroup of the tiled kernel
+__device__ unsigned long long g_h8_prof[8];
+#define H8_PROF_MARK(i)                                         \
+  {                                                             \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+    asm volatile("" ::: "memory");                              \
+    prof_acc[i] += t_now - prof_t;                              \
+    prof_t = t_now;                                             \
+  }
+#else
+#define H8_PROF_MARK(i)
+#endif
+
 // one global_load_lds_dwordx4: lane l copies the 16 bytes at its own `gsrc` to LDS address `ldst_wave_base + 16 l`
 #define SLU_GLDS16(gsrc, ldst_wave_base)                                                                  \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),                 \
@@ -157,11 +171,13 @@ __device__ __forceinline__ void store_tile_full(const H8Args& a, const f32x16& a
 
 // -----------------------------------------------------------------------------------------------------------
 // Tiled kernel, persistent, LDS-DMA staged.  Workgroup = WM x WN waves; output tile = TH rows x 64 columns x
-// (32 WM MB) channels.  A workgroup walks a contiguous run of tiles (consecutive along the azimuth, so neighbouring
-// halos hit L2).  The unit of staging is a chunk = one K-step (16 channels): the input tile (2 channel blocks,
-// halo included) and the weight fragments are copied global -> LDS by global_load_lds (no staging registers),
-// into the buffer the previous chunk is not using, while the T MFMA steps of the current chunk run; the chunk
-// after a tile's last one is the first chunk of the NEXT tile, so loads stay in flight across the epilogue.
+// (32 WM MB) channels.  Tiles are dealt to the resident workgroups round-robin (tile = w + i * #workgroups, the 32
+// workgroups of an XCD side by side along the azimuth), so at any moment the chip works on one compact band of the
+// image: neighbouring halos meet in L2 and DRAM sees long contiguous rows.  The unit of staging is a chunk = one
+// K-step (16 channels): the input tile (2 channel blocks, halo included) and the weight fragments are copied
+// global -> LDS by global_load_lds (no staging registers), into the buffer the previous chunk is not using, piece
+// by piece BETWEEN the taps of the current chunk's MFMA phase; the chunk after a tile's last one is the first
+// chunk of the NEXT tile, so loads stay in flight across the epilogue.
 // One barrier per chunk.  WRES: the weight fragments of ALL K-steps stay in LDS for the whole kernel (small
 // layers).  SCALED: per-(image, channel) multipliers (Dropout2d on a concatenated input) are applied to the B
 // fragments after the LDS read.
@@ -190,13 +206,19 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
   const int wm = wave / WN, wn = wave % WN;
   const int mblk0 = blockIdx.y * MBLK;
   // contiguous run of tiles of this workgroup; workgroups that share an XCD (blockIdx.x % 8) get neighbouring runs
-  int t_beg, t_end;
+  int t_beg, t_end, t_step = 1;
   {
     const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
     const int w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
     const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
-    t_beg = (int)(nt * w / nwg);
-    t_end = (int)(nt * (w + 1) / nwg);
+    if (a.order) {      // interleaved: at any moment the resident workgroups cover a compact band of the image
+      t_step = nwg;
+      t_beg = w;
+      t_end = w < nt ? w + (int)((nt - w + nwg - 1) / nwg) * nwg : w;
+    } else {
+      t_beg = (int)(nt * w / nwg);
+      t_end = (int)(nt * (w + 1) / nwg);
+    }
   }
   if (t_beg >= t_end) return;
 
@@ -239,47 +261,61 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
     pc_rc[i] = r | (c << 8) | ((g2 & 1) << 16) | ((e < NREC_B ? 1 : 0) << 17);
     pc_off[i] = r * a.W + c;
   }
-  // LDS-DMA of chunk q of tile tp into input buffer `buf` (and, unless WRES, its weight fragments into weight buffer `buf`)
-  auto stage = [&](const TilePos& tp, int q, int buf) {
+  // LDS-DMA of chunk q of tile tp into input buffer `buf` (and, unless WRES, its weight fragments into weight buffer `buf`),
+  // in NPIECE pieces per wave: stage_begin fixes the wave-uniform part, stage_piece(i) issues one global_load_lds.  The
+  // pieces of chunk c+1 are issued BETWEEN the taps of chunk c (see the tap loops): when all of them came in one burst
+  // right after the barrier, the eight waves queued on the CU's single address pipe while the matrix cores idled
+  // (measured with -DSLU_H8_PROF: 25 % of the kernel in that burst, another 20 % in the barrier behind it).
+  constexpr int NPIECE = NIB + (WRES ? 0 : NIA);
+  constexpr int PPT = (NPIECE + T - 1) / T;          // pieces issued after each tap
+  uintptr_t st_base0 = 0, st_base1 = 0;
+  bool st_live0 = false, st_live1 = false, st_on = false;
+  int st_x0 = 0, st_y0 = 0, st_q = 0;
+  uint4 *st_db = s_b, *st_da = s_a;
+  auto stage_begin = [&](const TilePos& tp, int q, int buf) {
     int img[SLU_MAX_SRC];
 #pragma unroll
     for (int s = 0; s < SLU_MAX_SRC; ++s) img[s] = (s < a.nsrc && a.src[s].nb) ? tp.n % a.src[s].nb : tp.n;
     // wave-uniform: the two channel blocks of this K-step, as byte addresses of the record at tile-image position (0, 0)
-    uintptr_t base[2];
-    bool live[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int g = 2 * q + h;
-      live[h] = g < a.Gin;
-      const SrcSel p = select_src(a, img, live[h] ? g : 0);
-      base[h] = reinterpret_cast<uintptr_t>(p.ptr) +
-                16 * ((long long)(((size_t)p.ns * p.G + p.gl) * HW) + (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD));
-    }
-    const uintptr_t zero = reinterpret_cast<uintptr_t>(&g_zero_rec);
-    uint4* db = s_b + buf * NB_ALLOC;
-#pragma unroll
-    for (int i = 0; i < NIB; ++i) {
+    const long long org = (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD);
+    st_live0 = 2 * q < a.Gin;
+    st_live1 = 2 * q + 1 < a.Gin;
+    const SrcSel p0 = select_src(a, img, st_live0 ? 2 * q : 0), p1 = select_src(a, img, st_live1 ? 2 * q + 1 : 0);
+    st_base0 = reinterpret_cast<uintptr_t>(p0.ptr) + 16 * ((long long)(((size_t)p0.ns * p0.G + p0.gl) * HW) + org);
+    st_base1 = reinterpret_cast<uintptr_t>(p1.ptr) + 16 * ((long long)(((size_t)p1.ns * p1.G + p1.gl) * HW) + org);
+    st_x0 = tp.x0 - PAD;
+    st_y0 = tp.y0 - PAD;
+    st_q = q;
+    st_db = s_b + buf * NB_ALLOC;
+    st_da = s_a + buf * NREC_A;
+    st_on = true;
+  };
+  auto stage_piece = [&](int i) {
+    if (i < NIB) {
       const int blk = i * NWAVE + wave;
       if (NBLK_B % NWAVE == 0 || blk < NBLK_B) {
         const int rc = pc_rc[i];
-        const int gy = tp.y0 - PAD + (rc & 255), gx = tp.x0 - PAD + ((rc >> 8) & 255);
+        const int gy = st_y0 + (rc & 255), gx = st_x0 + ((rc >> 8) & 255);
         const bool h1 = (rc >> 16) & 1;
-        const bool ok = (rc >> 17) && (h1 ? live[1] : live[0]) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        const uintptr_t src = ok ? (h1 ? base[1] : base[0]) + 16 * (long long)pc_off[i] : zero;
-        SLU_GLDS16(reinterpret_cast<const uint4*>(src), db + blk * 64);
+        const bool ok = (rc >> 17) && (h1 ? st_live1 : st_live0) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const uintptr_t src = ok ? (h1 ? st_base1 : st_base0) + 16 * (long long)pc_off[i] : reinterpret_cast<uintptr_t>(&g_zero_rec);
+        SLU_GLDS16(reinterpret_cast<const uint4*>(src), st_db + blk * 64);
+      }
+    } else if constexpr (!WRES) {
+      const int blk = (i - NIB) * NWAVE + wave;                         // = m * T + tap
+      if (NBLK_A % NWAVE == 0 || blk < NBLK_A) {
+        const int m = blk / T;
+        const uint4* src = mblk0 + m < a.nmblk ? a.wpack + (((size_t)(mblk0 + m) * nks + st_q) * T + (blk - m * T)) * 64 + lane : &g_zero_rec;
+        SLU_GLDS16(src, st_da + blk * 64);
       }
     }
-    if constexpr (!WRES) {
-      uint4* da = s_a + buf * NREC_A;
+  };
+  // the pieces that go after tap `tap` (compile-time indices once the tap loop is unrolled)
+  auto stage_after_tap = [&](int tap) {
+    if (st_on) {
 #pragma unroll
-      for (int i = 0; i < NIA; ++i) {
-        const int blk = i * NWAVE + wave;                               // = m * T + tap
-        if (NBLK_A % NWAVE == 0 || blk < NBLK_A) {
-          const int m = blk / T;
-          const uint4* src = mblk0 + m < a.nmblk ? a.wpack + (((size_t)(mblk0 + m) * nks + q) * T + (blk - m * T)) * 64 + lane : &g_zero_rec;
-          SLU_GLDS16(src, da + blk * 64);
-        }
-      }
+      for (int k = 0; k < PPT; ++k)
+        if (tap * PPT + k < NPIECE) stage_piece(tap * PPT + k);
     }
   };
   // per-channel multipliers of image n as fp16, one record per channel block (SCALED)
@@ -311,14 +347,19 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
     }
   }
   TilePos cur = decode(t_beg), nxt = cur;
-  stage(cur, 0, 0);
+  stage_begin(cur, 0, 0);
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) stage_piece(i);
   int buf = 0;
   constexpr int NST = MB * NB * 4;                   // stores of a tile's epilogue, per wave (h8 output: every lane stores)
   constexpr bool PRE = MB == 1 && !F32OUT;           // residual of the tile prefetched before its last MFMA phase
   const uint2* resid2 = reinterpret_cast<const uint2*>(resid);
   uint2 rv[PRE ? NB : 1][4];
 
-  for (int tile = t_beg; tile < t_end; ++tile) {
+#ifdef SLU_H8_PROF
+  unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
+  for (int tile = t_beg; tile < t_end; tile += t_step) {
     f32x16 acc[MB][NB];                                // per tile (not carried around the loop: keeps it in the MFMA registers)
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -326,7 +367,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
-    const int spar = (tile - t_beg) & 1;
+    const int spar = ((tile - t_beg) / t_step) & 1;
     if constexpr (SCALED) stage_scales(cur.n, spar);
     for (int q = 0; q < nks; ++q) {
       // Chunk (tile, q) has landed and nobody reads the other buffer any more.  vmcnt counts loads, LDS-DMA and stores in
@@ -335,13 +376,16 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
       if (!F32OUT && q == 0 && tile != t_beg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST < 63 ? NST : 63) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      H8_PROF_MARK(0)                                    // waiting for the chunk's DMA (and, at q = 0, the epilogue before it)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      H8_PROF_MARK(1)                                    // barrier
+      st_on = false;
       if (q + 1 < nks) {
-        stage(cur, q + 1, buf ^ 1);
-      } else if (tile + 1 < t_end) {
-        nxt = decode(tile + 1);
-        stage(nxt, 0, buf ^ 1);
+        stage_begin(cur, q + 1, buf ^ 1);
+      } else if (tile + t_step < t_end) {
+        nxt = decode(tile + t_step);
+        stage_begin(nxt, 0, buf ^ 1);
       }
       if constexpr (PRE) {
         if (resid && q == nks - 1) {
@@ -359,6 +403,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
           }
         }
       }
+      H8_PROF_MARK(2)                                    // issuing the next chunk's DMA (+ residual prefetch)
       const uint4* sb = s_b + buf * NB_ALLOC + bbase;
       const uint4* sa = s_a + abase + (WRES ? q * T * 64 : buf * NREC_A);
       half8 sc;
@@ -393,6 +438,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
                 __builtin_amdgcn_sched_group_barrier(0x100, (MB + NB + MB * NB - 1) / (MB * NB), 0);
               }
             }
+            stage_after_tap(tap);
           }
         } else {
 #pragma unroll
@@ -414,10 +460,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
               __builtin_amdgcn_sched_group_barrier(0x100, (MB + NB + MB * NB - 1) / (MB * NB), 0);
             }
+            stage_after_tap(tap);
           }
         }
       }
       buf ^= 1;
+      H8_PROF_MARK(3)                                    // LDS reads + MFMAs of the chunk
     }
     {
 #pragma unroll
@@ -437,8 +485,15 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
         }
       }
     }
+    H8_PROF_MARK(4)                                      // epilogue
     cur = nxt;
   }
+#ifdef SLU_H8_PROF
+  if (tid == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_h8_prof[i], prof_acc[i]);
+    atomicAdd(&g_h8_prof[5], 1ull);
+  }
+#endif
 }
 
 // -----------------------------------------------------------------------------------------------------------
@@ -835,6 +890,8 @@ int launch_h8_k(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
   if (SCALED && a.Gin > 64) return SLU_EUNSUPPORTED;
   a.tiles_x = (a.W + 63) / 64;
   a.tiles_y = (a.H + TH - 1) / TH;
+  static const int order = [] { const char* e = getenv("SLU_H8_ORDER"); return e ? atoi(e) : 1; }();      // 0 is kept for A/B runs
+  a.order = order;
   const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
   const int gy = (a.nmblk + MBLK - 1) / MBLK;
   if (nt <= 0 || nt > 0x7fffffffLL || gy > 65535) return SLU_EUNSUPPORTED;
@@ -878,6 +935,8 @@ const int CFG_TABLE[CFG_COUNT][4] = {{1, 1, 8, 2}, {2, 1, 8, 2}, {2, 2, 4, 2}, {
 
 int choose_h8(const H8Args& a) {
   const long long want = 256;
+  static const int forced = [] { const char* e = getenv("SLU_H8_CFG"); return e ? atoi(e) : -1; }();      // development aid
+  if (forced >= 0 && forced < CFG_COUNT) return forced;
   if (a.nmblk >= 4) {
     if (a.H >= 8 && wg_count(a, 8, 4) >= want) return CFG_M128_TH8;
     if (wg_count(a, 4, 4) >= want) return CFG_M128_TH4;
@@ -1033,6 +1092,14 @@ extern "C" int slu_conv2d_h8_kernel_name(const slu_conv_h8_desc* d, char* buf, s
            any_scale(d) ? "true" : "false", wres ? "true" : "false");
   return SLU_OK;
 }
+
+#ifdef SLU_H8_PROF
+extern "C" int slu_h8_prof_read(unsigned long long* out8) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_h8_prof), sizeof(unsigned long long) * 8) != hipSuccess) return SLU_ELAUNCH;
+  unsigned long long z[8] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_h8_prof), z, sizeof(z)) == hipSuccess ? SLU_OK : SLU_ELAUNCH;
+}
+#endif
 
 extern "C" int slu_nchw_to_h8(const float* x, const float* scale, void* y, int N, int C, int H, int W, slu_stream_t stream) {
   if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ((uintptr_t)y & 15)) return SLU_EINVAL;

@@ -10,15 +10,17 @@ launches, which keeps the small 4x128 ... 16x512 feature maps from under-filling
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
+
 import torch.nn as nn
 
 from semanticlidarunc_amd import ops
 
 EPS = 1e-12
 _DROPOUT_TYPES = (nn.Dropout, nn.Dropout2d, nn.Dropout3d, nn.AlphaDropout, nn.FeatureAlphaDropout)
-MAX_STACK = 16   # at most this many passes of one batch are stacked per launch sequence
+MAX_STACK = int(os.environ.get("SLU_MC_MAX_STACK", "16"))   # at most this many passes of one batch are stacked per launch sequence
 
 
 def set_dropout_mode(module: nn.Module, train: bool) -> None:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-kernel table from rocprofv3 --pmc CSV output directories: `python tools/pmc_table.py DIR [DIR ...]`.
+"""Per-kernel table from rocprofv3 --pmc output directories (CSV or rocpd .db): `python tools/pmc_table.py DIR [DIR ...]`.
 Joins counter_collection.csv (summing a counter over its dimensions per dispatch) with kernel_trace.csv durations and
 prints, per dispatch of the LAST iteration, duration and every collected counter."""
 import csv
@@ -9,7 +9,22 @@ import sys
 from collections import OrderedDict, defaultdict
 
 
+def load_rocpd(db):
+    """The same three maps from a rocpd SQLite file (rocprofv3's default output when no --output-format is given)."""
+    import sqlite3
+    con = sqlite3.connect(db)
+    dur, name = {}, {}
+    vals = defaultdict(lambda: defaultdict(float))
+    for did, nm, cn, v, t0, t1 in con.execute("select dispatch_id, kernel_name, counter_name, value, start, end from counters_collection"):
+        dur[did] = (t1 - t0) / 1e3
+        name[did] = nm
+        vals[did][cn] += float(v)
+    return dur, name, vals
+
+
 def load(d):
+    if not glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        return load_rocpd(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0])
     cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     dur, name = {}, {}
