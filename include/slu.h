@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 11
+#define SLU_ABI_VERSION 12
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -348,6 +348,18 @@ int slu_dirichlet_loss_fwd(const float* alpha, const int64_t* labels, int B, int
                            int64_t ignore_index, double* sum, int64_t* count, slu_stream_t stream);
 int slu_dirichlet_loss_bwd(const float* alpha, const int64_t* labels, int B, int C, int HW, int kind, float param, float eps, int has_ignore,
                            int64_t ignore_index, const float* gscale, float* grad_alpha, slu_stream_t stream);
+
+/* The same pass with a parameter vector (HOST floats) and the two gated regularisers of the Dirichlet path:
+ *   kind 5 ComplementKLUniform (losses/dirichlet_losses.py:228-314): w(p_y) * KL(p_off / (1 - p_y) || U); params = {gamma, tau, sigma,
+ *          s_target (< 0: no evidence gate), normalize (0/1), detach_uncert (0/1)}; mean over the valid pixels; 0 when C <= 2.
+ *   kind 6 WrongLowEvidence (losses/regularizers.py:218-289): gate * relu(ln a0 - ln(C + s_low + eps))^2 with gate = [argmax != y] *
+ *          sigmoid((p_max - p_y - margin) / k) (k = 0: hard margin; margin <= 0: no margin gate); params = {s_low, margin, k};
+ *          the mean runs over sum(gate): fwd writes sums2 = {sum of values, sum of gates} and the caller divides by max(sums2[1], 1).
+ * kinds 0-4 take params = {param} (or none).  bwd: gscale = upstream gradient / the forward's denominator (DEVICE). */
+int slu_dirichlet_loss_fwd_ex(const float* alpha, const int64_t* labels, int B, int C, int HW, int kind, const float* params, int nparams, float eps,
+                              int has_ignore, int64_t ignore_index, double* sums2, int64_t* count, slu_stream_t stream);
+int slu_dirichlet_loss_bwd_ex(const float* alpha, const int64_t* labels, int B, int C, int HW, int kind, const float* params, int nparams, float eps,
+                              int has_ignore, int64_t ignore_index, const float* gscale, float* grad_alpha, slu_stream_t stream);
 
 /* ---- spherical projection of a point cloud into the range image (dataset/utils.py:61-67,288-349) ------------------
  * pc: float64 [N][C] (x, y, z, then any channels: intensity, label ...; the reference's dataloader concatenates to float64,

@@ -90,3 +90,45 @@ def loss_kl_off_uniform(alpha, target, ignore_index=None, eps=1e-8):
     s = a.sum(dim=1, keepdim=True)
     kl = torch.lgamma(s) - torch.lgamma(a).sum(dim=1, keepdim=True) + ((a - 1.0) * (torch.digamma(a) - torch.digamma(s))).sum(dim=1, keepdim=True)
     return kl.squeeze(1).mean()
+
+
+def loss_complement_kl(alpha, target, ignore_index=0, gamma=2.0, tau=0.55, sigma=0.12, s_target=None, normalize=True, eps=1e-8, detach_uncert=True):
+    """losses/dirichlet_losses.py:228-314: gate(p_y) * KL(off-class conditional || uniform over C-1), mean over valid pixels."""
+    c = alpha.shape[1]
+    valid = torch.ones_like(target, dtype=torch.bool) if ignore_index is None else target != ignore_index
+    if int(valid.sum()) == 0 or c <= 2:
+        return alpha.sum() * 0.0
+    idx = torch.where(valid, target, torch.zeros_like(target)).unsqueeze(1)
+    a0 = alpha.sum(dim=1, keepdim=True) + eps
+    p = alpha / a0
+    py = p.gather(1, idx).clamp_min(eps)
+    cond = p.scatter(1, idx, 0.0) / (1.0 - py).clamp_min(eps)              # distribution over the C-1 other classes
+    kl = (cond * cond.clamp_min(eps).log()).sum(dim=1) + math.log(c - 1)
+    if normalize:
+        kl = kl / math.log(c - 1)
+    pg = py.detach() if detach_uncert else py
+    w = ((1.0 - pg).pow(gamma) * torch.sigmoid((tau - pg) / sigma)).squeeze(1)
+    if s_target is not None:
+        w = w * (float(s_target) / (a0.detach().squeeze(1) + float(s_target)))
+    return _masked_mean(w * kl, target, ignore_index)
+
+
+def loss_wrong_low_evidence(alpha, target, ignore_index=None, s_low=0.0, margin=0.05, soft_margin_k=0.08, eps=1e-8):
+    """losses/regularizers.py:218-289: squared hinge of ln(alpha0) above ln(C + s_low + eps) on (softly) confidently wrong pixels,
+    averaged over the sum of the gates; the gates carry no gradient."""
+    c = alpha.shape[1]
+    valid = torch.ones_like(target, dtype=torch.bool) if ignore_index is None else target != ignore_index
+    if int(valid.sum()) == 0:
+        return alpha.sum() * 0.0
+    a0 = alpha.sum(dim=1, keepdim=True).clamp_min(eps)
+    with torch.no_grad():
+        p = alpha.detach() / a0.detach()
+        top, pred = p.max(dim=1)
+        gap = top.clamp_min(eps) - p.gather(1, target.unsqueeze(1)).squeeze(1).clamp_min(eps)
+        if margin > 0.0:
+            soft = torch.sigmoid((gap - margin) / soft_margin_k) if soft_margin_k > 0.0 else (gap > margin).float()
+        else:
+            soft = torch.ones_like(gap)
+        gate = (pred != target).float() * soft * valid.float()
+    hinge = torch.relu(a0.log().squeeze(1) - math.log(c + s_low + eps)).pow(2) * gate
+    return hinge.sum() / gate.sum().clamp_min(1.0)

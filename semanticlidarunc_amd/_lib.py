@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -137,6 +137,10 @@ SIGNATURES = {
                                          c_stream]),
     "slu_dirichlet_loss_bwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int64, c_f32p, c_f32p,
                                          c_stream]),
+    "slu_dirichlet_loss_fwd_ex": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_int, C.c_int64,
+                                            c_f64p, c_i64p, c_stream]),
+    "slu_dirichlet_loss_bwd_ex": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_int, C.c_int64,
+                                            c_f32p, c_f32p, c_stream]),
     "slu_spherical_projection_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_spherical_projection": (C.c_int, [c_f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_size_t,
                                            c_f32p, c_f64p, c_stream]),

@@ -1,8 +1,8 @@
 """Drop-ins for the per-pixel Dirichlet losses of the reference (``src/losses/dirichlet_losses.py``:
-``NLLDirichletCategorical`` :73-119, ``DigammaDirichletCE`` :122-167, ``BrierDirichlet`` :174-221, ``DirichletMSELoss`` :317-385):
+``NLLDirichletCategorical`` :73-119, ``DigammaDirichletCE`` :122-167, ``BrierDirichlet`` :174-221, ``ComplementKLUniform`` :228-314,
+``DirichletMSELoss`` :317-385):
 same constructors and ``forward(alpha, target)``; value and d/d alpha are one fused HIP pass each (``csrc/dirichlet_loss.hip``)
-behind a re-entrant ``torch.autograd.Function``.  ``ignore_index``: None or one int (what the reference's Trainer passes);
-``ComplementKLUniform`` is not mirrored."""
+behind a re-entrant ``torch.autograd.Function``.  ``ignore_index``: None or one int (what the reference's Trainer passes)."""
 from __future__ import annotations
 
 from typing import Optional
@@ -31,6 +31,29 @@ class _DirichletLossFn(torch.autograd.Function):
         kind, param, eps, ignore_index = ctx.cfg
         gscale = (g.detach().reshape(1).to(torch.float64) / n.clamp_min(1).to(torch.float64)).to(torch.float32)
         return ops.dirichlet_loss_bwd(a, lab, kind, param, eps, ignore_index, gscale), None, None, None, None, None
+
+
+class _DirichletLossExFn(torch.autograd.Function):
+    """The parameter-vector form (kinds "complement_kl", "wrong_low_evidence"); `gated`: the mean runs over the sum of the gates."""
+
+    @staticmethod
+    def forward(ctx, alpha, target, kind, params, eps, ignore_index, gated):
+        a = alpha.detach().float().contiguous()
+        if target.dim() == 4 and target.size(1) == 1:
+            target = target[:, 0]
+        lab = target.detach().to(device=a.device, dtype=torch.int64).contiguous()
+        s, n = ops.dirichlet_loss_fwd_ex(a, lab, kind, params, eps, ignore_index)
+        den = s[1:2].clamp_min(1.0) if gated else n.clamp_min(1).to(torch.float64)
+        ctx.save_for_backward(a, lab, den)
+        ctx.cfg = (kind, tuple(params), eps, ignore_index)
+        return (s[0:1] / den).to(torch.float32).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, lab, den = ctx.saved_tensors
+        kind, params, eps, ignore_index = ctx.cfg
+        gscale = (g.detach().reshape(1).to(torch.float64) / den).to(torch.float32)
+        return ops.dirichlet_loss_bwd_ex(a, lab, kind, params, eps, ignore_index, gscale), None, None, None, None, None, None
 
 
 def _check_ignore(ignore_index):
@@ -72,6 +95,27 @@ class BrierDirichlet(nn.Module):
 
     def forward(self, alpha, target):
         return _DirichletLossFn.apply(alpha, target, "brier", -1.0 if self.s_ref is None else float(self.s_ref), self.eps, self.ignore_index)
+
+
+class ComplementKLUniform(nn.Module):
+    """w(p_y) * KL(p_off / (1 - p_y) || uniform over the C - 1 off classes), w = (1 - p_y)^gamma * sigmoid((tau - p_y) / sigma)
+    [* s_target / (alpha0 + s_target)], mean over valid pixels; 0 for C <= 2 (reference :228-314, same defaults)."""
+
+    def __init__(self, ignore_index: Optional[int] = 0, gamma: float = 2.0, tau: float = 0.55, sigma: float = 0.12,
+                 s_target: Optional[float] = None, normalize: bool = True, eps: float = 1e-8, detach_uncert: bool = True):
+        super().__init__()
+        self.ignore_index = _check_ignore(ignore_index)
+        self.gamma, self.tau, self.sigma = float(gamma), float(tau), float(sigma)
+        self.s_target, self.normalize, self.eps, self.detach_uncert = s_target, bool(normalize), eps, bool(detach_uncert)
+        if s_target is not None and float(s_target) < 0:
+            raise ValueError("s_target must be non-negative")
+
+    def forward(self, alpha, target):
+        if alpha.shape[1] <= 2:
+            return alpha.sum() * 0.0
+        params = (self.gamma, self.tau, self.sigma, -1.0 if self.s_target is None else float(self.s_target), float(self.normalize),
+                  float(self.detach_uncert))
+        return _DirichletLossExFn.apply(alpha, target, "complement_kl", params, self.eps, self.ignore_index, False)
 
 
 class DirichletMSELoss(nn.Module):

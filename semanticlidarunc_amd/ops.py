@@ -775,7 +775,7 @@ def tversky_bwd(x: torch.Tensor, labels: torch.Tensor, model_act: str, ignore_in
 # ------------------------------------------------------------------------------------------------
 # per-pixel Dirichlet losses (losses/dirichlet_losses.py, losses/regularizers.py)
 # ------------------------------------------------------------------------------------------------
-DIRICHLET_LOSS_KINDS = {"nll_dircat": 0, "digamma_ce": 1, "brier": 2, "mse": 3, "kl_off_uniform": 4}
+DIRICHLET_LOSS_KINDS = {"nll_dircat": 0, "digamma_ce": 1, "brier": 2, "mse": 3, "kl_off_uniform": 4, "complement_kl": 5, "wrong_low_evidence": 6}
 
 
 def _dirichlet_loss_args(alpha, labels):
@@ -804,6 +804,35 @@ def dirichlet_loss_bwd(alpha: torch.Tensor, labels: torch.Tensor, kind: str, par
     check(_lib.load().slu_dirichlet_loss_bwd(alpha.data_ptr(), labels.data_ptr(), b, c, h * w, DIRICHLET_LOSS_KINDS[kind], float(param), float(eps),
                                              0 if ignore_index is None else 1, 0 if ignore_index is None else int(ignore_index),
                                              gscale.data_ptr(), g.data_ptr(), _stream()), "slu_dirichlet_loss_bwd")
+    return g
+
+
+def _c_params(params):
+    import ctypes as C
+    vals = [float(v) for v in params]
+    return (C.c_float * max(1, len(vals)))(*vals), len(vals)
+
+
+def dirichlet_loss_fwd_ex(alpha: torch.Tensor, labels: torch.Tensor, kind: str, params, eps: float, ignore_index):
+    """-> (sums float64 [2] = {sum of values, sum of gates (kind "wrong_low_evidence")}, count int64 [1]); `params` per include/slu.h."""
+    b, c, h, w = _dirichlet_loss_args(alpha, labels)
+    s = torch.empty(2, dtype=torch.float64, device=alpha.device)
+    n = torch.empty(1, dtype=torch.int64, device=alpha.device)
+    arr, k = _c_params(params)
+    check(_lib.load().slu_dirichlet_loss_fwd_ex(alpha.data_ptr(), labels.data_ptr(), b, c, h * w, DIRICHLET_LOSS_KINDS[kind], arr, k, float(eps),
+                                                0 if ignore_index is None else 1, 0 if ignore_index is None else int(ignore_index), s.data_ptr(),
+                                                n.data_ptr(), _stream()), "slu_dirichlet_loss_fwd_ex")
+    return s, n
+
+
+def dirichlet_loss_bwd_ex(alpha: torch.Tensor, labels: torch.Tensor, kind: str, params, eps: float, ignore_index, gscale: torch.Tensor):
+    b, c, h, w = _dirichlet_loss_args(alpha, labels)
+    _req(gscale, "gscale")
+    g = torch.empty_like(alpha)
+    arr, k = _c_params(params)
+    check(_lib.load().slu_dirichlet_loss_bwd_ex(alpha.data_ptr(), labels.data_ptr(), b, c, h * w, DIRICHLET_LOSS_KINDS[kind], arr, k, float(eps),
+                                                0 if ignore_index is None else 1, 0 if ignore_index is None else int(ignore_index),
+                                                gscale.data_ptr(), g.data_ptr(), _stream()), "slu_dirichlet_loss_bwd_ex")
     return g
 
 

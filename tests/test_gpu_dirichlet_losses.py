@@ -7,7 +7,7 @@ import torch
 from conftest import golden
 from oracle import dirichlet as odir
 from semanticlidarunc_amd.losses import dirichlet_losses as dl
-from semanticlidarunc_amd.losses.regularizers import KL_offClasses_to_uniform
+from semanticlidarunc_amd.losses.regularizers import KL_offClasses_to_uniform, WrongLowEvidence
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,12 @@ def _t(a):
 def _modules():
     return {"nll_dircat": dl.NLLDirichletCategorical(ignore_index=0), "digamma_ce": dl.DigammaDirichletCE(ignore_index=0),
             "brier": dl.BrierDirichlet(ignore_index=0), "brier_sref40": dl.BrierDirichlet(ignore_index=0, s_ref=40.0),
-            "mse": dl.DirichletMSELoss(ignore_index=0), "kl_off_uniform": KL_offClasses_to_uniform(ignore_index=0)}
+            "mse": dl.DirichletMSELoss(ignore_index=0), "kl_off_uniform": KL_offClasses_to_uniform(ignore_index=0),
+            "complement_kl": dl.ComplementKLUniform(ignore_index=0, gamma=1.25, tau=0.65, sigma=0.15),        # the Trainer's settings (trainer.py:339)
+            "complement_kl_gated": dl.ComplementKLUniform(ignore_index=0, s_target=30.0, normalize=False, detach_uncert=False),
+            "wrong_low_evidence": WrongLowEvidence(ignore_index=0),
+            "wrong_low_evidence_hard": WrongLowEvidence(ignore_index=0, s_low=4.0, margin=0.1, soft_margin_k=0.0),
+            "wrong_low_evidence_nomargin": WrongLowEvidence(ignore_index=None, margin=0.0)}
 
 
 def test_against_reference_golden(cuda):
@@ -38,6 +43,14 @@ def test_against_reference_golden(cuda):
     z.backward()
     assert float(z.detach()) == 0.0 and float(a.grad.abs().max()) == 0.0
     assert float(dl.DirichletMSELoss()(torch.ones(1, 2, 4, 4, device=cuda), torch.zeros(1, 4, 4, dtype=torch.int64, device=cuda))) == 0.0   # C <= 2
+    assert float(dl.ComplementKLUniform(ignore_index=None)(torch.ones(1, 2, 4, 4, device=cuda), torch.zeros(1, 4, 4, dtype=torch.int64, device=cuda))) == 0.0
+    # every prediction right: no gate fires, the loss and its gradient are exactly 0 (the reference divides by max(sum(gate), 1))
+    right = torch.ones(1, 20, 4, 8, device=cuda)
+    right[:, 3] = 50.0
+    right.requires_grad_(True)
+    w = WrongLowEvidence()(right, torch.full((1, 4, 8), 3, dtype=torch.int64, device=cuda))
+    w.backward()
+    assert float(w.detach()) == 0.0 and float(right.grad.abs().max()) == 0.0
     with pytest.raises(NotImplementedError):
         KL_offClasses_to_uniform(with_conf_weighting=True)
     with pytest.raises(NotImplementedError):
@@ -53,7 +66,12 @@ def test_full_size_against_oracle_and_reentrant_backward(cuda):
     alpha = 1.0 + torch.nn.functional.softplus(torch.randn(2, 20, 64, 2048, generator=gen) * 2.0) * 10.0
     ofn = {"nll_dircat": lambda a: odir.loss_nll_dircat(a, lab, 0), "digamma_ce": lambda a: odir.loss_digamma_ce(a, lab, 0),
            "brier": lambda a: odir.loss_brier(a, lab, 0), "brier_sref40": lambda a: odir.loss_brier(a, lab, 0, 40.0),
-           "mse": lambda a: odir.loss_mse(a, lab, 0), "kl_off_uniform": lambda a: odir.loss_kl_off_uniform(a, lab, 0)}
+           "mse": lambda a: odir.loss_mse(a, lab, 0), "kl_off_uniform": lambda a: odir.loss_kl_off_uniform(a, lab, 0),
+           "complement_kl": lambda a: odir.loss_complement_kl(a, lab, 0, 1.25, 0.65, 0.15),
+           "complement_kl_gated": lambda a: odir.loss_complement_kl(a, lab, 0, s_target=30.0, normalize=False, detach_uncert=False),
+           "wrong_low_evidence": lambda a: odir.loss_wrong_low_evidence(a, lab, 0),
+           "wrong_low_evidence_hard": lambda a: odir.loss_wrong_low_evidence(a, lab, 0, 4.0, 0.1, 0.0),
+           "wrong_low_evidence_nomargin": lambda a: odir.loss_wrong_low_evidence(a, lab, None, margin=0.0)}
     for name, mod in _modules().items():
         ao = alpha.clone().requires_grad_(True)
         lo = ofn[name](ao)

@@ -210,7 +210,12 @@ def test_dirichlet_losses_golden():
     lab, alpha = torch.from_numpy(g["labels"]), torch.from_numpy(g["alpha"])
     fns = {"nll_dircat": lambda a: odir.loss_nll_dircat(a, lab, 0), "digamma_ce": lambda a: odir.loss_digamma_ce(a, lab, 0),
            "brier": lambda a: odir.loss_brier(a, lab, 0), "brier_sref40": lambda a: odir.loss_brier(a, lab, 0, 40.0),
-           "mse": lambda a: odir.loss_mse(a, lab, 0), "kl_off_uniform": lambda a: odir.loss_kl_off_uniform(a, lab, 0)}
+           "mse": lambda a: odir.loss_mse(a, lab, 0), "kl_off_uniform": lambda a: odir.loss_kl_off_uniform(a, lab, 0),
+           "complement_kl": lambda a: odir.loss_complement_kl(a, lab, 0, 1.25, 0.65, 0.15),
+           "complement_kl_gated": lambda a: odir.loss_complement_kl(a, lab, 0, s_target=30.0, normalize=False, detach_uncert=False),
+           "wrong_low_evidence": lambda a: odir.loss_wrong_low_evidence(a, lab, 0),
+           "wrong_low_evidence_hard": lambda a: odir.loss_wrong_low_evidence(a, lab, 0, 4.0, 0.1, 0.0),
+           "wrong_low_evidence_nomargin": lambda a: odir.loss_wrong_low_evidence(a, lab, None, margin=0.0)}
     for name, fn in fns.items():
         a = alpha.clone().requires_grad_(True)
         lo = fn(a)
@@ -222,6 +227,19 @@ def test_dirichlet_losses_golden():
     y = torch.tensor([[[1, 3]]])
     assert abs(float(odir.loss_nll_dircat(one, y)) - math.log(4.0)) < 1e-6
     assert abs(float(odir.loss_digamma_ce(one, y)) - (1.0 + 0.5 + 1.0 / 3.0)) < 1e-6
+    # complement-KL: off-class mass spread evenly -> 0; all of it on one off class -> ln(C-1) (1 when normalised), times the gate
+    even = torch.tensor([5.0, 1.0, 1.0, 1.0]).view(1, 4, 1, 1)
+    peak = torch.tensor([5.0, 3.0, 1e-9, 1e-9]).view(1, 4, 1, 1)
+    y0 = torch.zeros(1, 1, 1, dtype=torch.int64)
+    assert abs(float(odir.loss_complement_kl(even, y0, None))) < 1e-6
+    py = 5.0 / 8.0
+    gate = (1.0 - py) ** 2.0 / (1.0 + math.exp(-(0.55 - py) / 0.12))
+    assert abs(float(odir.loss_complement_kl(peak, y0, None)) - gate) < 1e-5
+    # wrong-low-evidence: a confidently wrong pixel with alpha0 = 2 C pays ln(2)^2 (hard margin: the gate is 1); a right one pays 0
+    wrong = torch.tensor([1.0, 7.0]).view(1, 2, 1, 1).repeat(1, 1, 1, 2) * torch.tensor([1.0, 0.5]).view(1, 1, 1, 2)
+    yw = torch.tensor([[[0, 1]]])
+    assert abs(float(odir.loss_wrong_low_evidence(wrong[..., :1] * 0.5, yw[..., :1], None, 0.0, 0.1, 0.0)) - math.log(2.0) ** 2) < 1e-5
+    assert float(odir.loss_wrong_low_evidence(wrong[..., 1:], yw[..., 1:], None, 0.0, 0.1, 0.0)) == 0.0
 
 
 def test_spherical_projection_golden_and_known_answers():

@@ -358,6 +358,15 @@ def main():
              ("brier_sref40", ref_dl.BrierDirichlet(ignore_index=0, s_ref=40.0), lambda a: odir2.loss_brier(a, dl_lab, 0, 40.0)),
              ("mse", ref_dl.DirichletMSELoss(ignore_index=0), lambda a: odir2.loss_mse(a, dl_lab, 0)),
              ("kl_off_uniform", ref_reg.KL_offClasses_to_uniform(ignore_index=0), lambda a: odir2.loss_kl_off_uniform(a, dl_lab, 0))]
+    pairs += [("complement_kl", ref_dl.ComplementKLUniform(ignore_index=0, gamma=1.25, tau=0.65, sigma=0.15),        # the Trainer's settings (trainer.py:339)
+               lambda a: odir2.loss_complement_kl(a, dl_lab, 0, 1.25, 0.65, 0.15)),
+              ("complement_kl_gated", ref_dl.ComplementKLUniform(ignore_index=0, s_target=30.0, normalize=False, detach_uncert=False),
+               lambda a: odir2.loss_complement_kl(a, dl_lab, 0, s_target=30.0, normalize=False, detach_uncert=False)),
+              ("wrong_low_evidence", ref_reg.WrongLowEvidence(ignore_index=0), lambda a: odir2.loss_wrong_low_evidence(a, dl_lab, 0)),
+              ("wrong_low_evidence_hard", ref_reg.WrongLowEvidence(ignore_index=0, s_low=4.0, margin=0.1, soft_margin_k=0.0),
+               lambda a: odir2.loss_wrong_low_evidence(a, dl_lab, 0, 4.0, 0.1, 0.0)),
+              ("wrong_low_evidence_nomargin", ref_reg.WrongLowEvidence(ignore_index=None, margin=0.0),
+               lambda a: odir2.loss_wrong_low_evidence(a, dl_lab, None, margin=0.0))]
     for name, ref_mod, ofn in pairs:
         ar = dl_alpha.clone().requires_grad_(True)
         lr = ref_mod(ar, dl_lab[:, None] if name == "mse" else dl_lab)          # [B,1,H,W] labels are accepted too
