@@ -326,6 +326,14 @@ int slu_ua_samples(const int64_t* labels, const int64_t* preds, const float* unc
 int slu_binned_counts(const float* u, const uint8_t* correct, long long n, const float* edges, int n_bins, int64_t* count, int64_t* n_correct,
                       slu_stream_t stream);
 
+/* ---- per-class sample lists (models/evaluator.py:211-232 UncertaintyPerClassAggregator.update) --------------------
+ * out_values = [values[labels == 0] ..., values[labels == 1] ..., ...] in scan order inside each class (what the reference's boolean
+ * masks on host copies return), counts int64 [C] = samples per class; labels outside [0, C) are dropped.  out_values holds n floats;
+ * C <= 32, n < 2^32. */
+size_t slu_group_by_class_workspace_bytes(long long n);
+int slu_group_by_class(const int64_t* labels, const float* values, long long n, int C, float* out_values, int64_t* counts, void* workspace,
+                       size_t workspace_bytes, slu_stream_t stream);
+
 /* ---- Tversky loss (models/losses.py:74-128, the 'Tversky' loss branch trainer.py:497-503) -----------------------
  * valid = 0 <= y < C and (no ignore or y != ignore_index); p by model_act (0 logits: softmax, 1 probs, 2 log_probs: exp);
  * per class over valid pixels S = sum p, TP = sum p [y = c], N = #[y = c];  tversky = (TP + s) / (TP + alpha (S - TP) + beta (N - TP) + s);

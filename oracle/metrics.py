@@ -175,3 +175,36 @@ def ua_binned(u, correct, edges):
     csum = np.histogram(u, bins=edges, weights=c)[0]
     acc = np.divide(csum, n, out=np.full_like(csum, np.nan, dtype=float), where=n > 0)
     return n, acc, 100.0 * n / max(1, u.size)
+
+
+class PerClassSamples:
+    """models/evaluator.py:191-262 (UncertaintyPerClassAggregator): per class the uncertainty values of the pixels labelled with it,
+    in scan order; with `cap` an approximate reservoir -- fill (a random subset of a batch that does not fit), then accept each new
+    sample with probability cap / seen and overwrite random slots.  One numpy Generator, classes visited in ascending order."""
+
+    def __init__(self, num_classes, cap=None, seed=0):
+        self.c, self.cap, self.rng = int(num_classes), cap, np.random.default_rng(seed)
+        self.values = [np.empty(0, np.float32) for _ in range(self.c)]
+        self.seen = [0] * self.c
+
+    def update(self, labels, uncertainty):
+        lab = np.asarray(labels).astype(np.int64).reshape(-1)
+        unc = np.asarray(uncertainty).astype(np.float32).reshape(-1)
+        for k in range(self.c):
+            new = unc[lab == k]
+            if new.size == 0:
+                continue
+            self.seen[k] += int(new.size)
+            have = self.values[k]
+            if self.cap is None:
+                self.values[k] = np.concatenate([have, new])
+            elif have.size < self.cap:
+                room = min(self.cap - have.size, new.size)
+                if room < new.size:
+                    new = new[self.rng.choice(new.size, size=room, replace=False)]
+                self.values[k] = np.concatenate([have, new])
+            else:
+                keep = self.rng.random(new.size) < min(1.0, float(self.cap) / float(self.seen[k] + 1e-9))
+                if keep.any():
+                    chosen = new[keep]
+                    have[self.rng.choice(self.cap, size=chosen.size, replace=False)] = chosen

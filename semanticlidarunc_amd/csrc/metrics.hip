@@ -219,3 +219,106 @@ extern "C" int slu_binned_counts(const float* u, const uint8_t* correct, long lo
                      reinterpret_cast<unsigned long long*>(count), reinterpret_cast<unsigned long long*>(n_correct));
   SLU_CHECK_LAUNCH();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Samples grouped by class, stable (models/evaluator.py:211-232 UncertaintyPerClassAggregator.update: the
+// reference pulls `uncertainty[labels == c]` for every class from host copies).  A wave owns a run of kRun consecutive
+// samples; lane c of the wave keeps the count / write cursor of class c, ranks inside a 64-sample step come from ballots.
+//   1. group_count_kernel:  counts[unit][c]
+//   2. group_scan_kernel:   counts -> exclusive offsets, class-major (class c's segment starts after all samples of classes < c)
+//   3. group_scatter_kernel: out[offset(unit, c) + rank] = value
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kRun = 1024;      // samples per wave
+
+__global__ __launch_bounds__(256) void group_count_kernel(const int64_t* __restrict__ labels, long long n, int C, long long nunit,
+                                                          unsigned* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= nunit) return;
+  unsigned mine = 0;
+  for (int it = 0; it < kRun / 64; ++it) {
+    const long long i = unit * kRun + it * 64 + lane;
+    const int64_t y = i < n ? labels[i] : -1;
+    for (int c = 0; c < C; ++c) {
+      const unsigned k = (unsigned)__popcll(__ballot(y == c));
+      if (lane == c) mine += k;
+    }
+  }
+  if (lane < C) counts[unit * 32 + lane] = mine;
+}
+
+// one workgroup; thread t walks units t, t + 1024, ...; per class a block-wide exclusive scan with a running carry
+__global__ __launch_bounds__(1024) void group_scan_kernel(unsigned* __restrict__ counts, long long nunit, int C, long long* __restrict__ totals) {
+  __shared__ unsigned long long s_w[16];
+  __shared__ unsigned long long s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int c = 0; c < C; ++c) {
+    const unsigned long long class_begin = s_carry;
+    for (long long base = 0; base < nunit; base += 1024) {
+      const long long u = base + tid;
+      const unsigned v = u < nunit ? counts[u * 32 + c] : 0u;
+      unsigned long long x = v;                                   // inclusive scan inside the wave
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+      }
+      if (lane == 63) s_w[wave] = x;
+      __syncthreads();
+      unsigned long long before = s_carry;
+      for (int w = 0; w < wave; ++w) before += s_w[w];
+      if (u < nunit) counts[u * 32 + c] = (unsigned)(before + x - v);      // exclusive offset (n < 2^32 checked by the host wrapper)
+      __syncthreads();
+      if (tid == 1023) s_carry = before + x;
+      __syncthreads();
+    }
+    if (tid == 0) totals[c] = (long long)(s_carry - class_begin);
+  }
+}
+
+__global__ __launch_bounds__(256) void group_scatter_kernel(const int64_t* __restrict__ labels, const float* __restrict__ values, long long n, int C,
+                                                            long long nunit, const unsigned* __restrict__ offsets, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= nunit) return;
+  unsigned cursor = lane < C ? offsets[unit * 32 + lane] : 0u;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int it = 0; it < kRun / 64; ++it) {
+    const long long i = unit * kRun + it * 64 + lane;
+    const int64_t y = i < n ? labels[i] : -1;
+    unsigned dst = 0;
+    for (int c = 0; c < C; ++c) {
+      const unsigned long long m = __ballot(y == c);
+      const unsigned start = __shfl(cursor, c);
+      if (y == c) dst = start + (unsigned)__popcll(m & lt);
+      if (lane == c) cursor += (unsigned)__popcll(m);
+    }
+    if (y >= 0 && y < C) out[dst] = values[i];
+  }
+}
+
+}  // namespace
+
+extern "C" size_t slu_group_by_class_workspace_bytes(long long n) {
+  const long long nunit = (n + kRun - 1) / kRun;
+  return (size_t)(nunit > 0 ? nunit : 1) * 32 * sizeof(unsigned);
+}
+
+extern "C" int slu_group_by_class(const int64_t* labels, const float* values, long long n, int C, float* out_values, int64_t* counts, void* workspace,
+                                  size_t workspace_bytes, slu_stream_t stream) {
+  if (!labels || !values || !out_values || !counts || !workspace || n <= 0 || C <= 0) return SLU_EINVAL;
+  if (C > 32 || n >= (1ll << 32)) return SLU_EUNSUPPORTED;
+  if (workspace_bytes < slu_group_by_class_workspace_bytes(n)) return SLU_EINVAL;
+  const long long nunit = (n + kRun - 1) / kRun;
+  unsigned* cnt = reinterpret_cast<unsigned*>(workspace);
+  hipStream_t st = slu_stream(stream);
+  const unsigned nb = (unsigned)((nunit + 3) / 4);
+  hipLaunchKernelGGL(group_count_kernel, dim3(nb), dim3(256), 0, st, labels, n, C, nunit, cnt);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, nunit, C, reinterpret_cast<long long*>(counts));
+  hipLaunchKernelGGL(group_scatter_kernel, dim3(nb), dim3(256), 0, st, labels, values, n, C, nunit, cnt, out_values);
+  SLU_CHECK_LAUNCH();
+}

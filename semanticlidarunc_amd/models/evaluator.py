@@ -1,4 +1,5 @@
-"""Mirrors of the reference's ``IoUEvaluator`` (src/models/evaluator.py:29-105) and ``UncertaintyAccuracyAggregator`` (:640-869).
+"""Mirrors of the reference's ``IoUEvaluator`` (src/models/evaluator.py:29-105), ``UncertaintyPerClassAggregator`` (:191-281) and
+``UncertaintyAccuracyAggregator`` (:640-869).
 
 ``update`` accumulates the [C,C] int64 confusion matrix (rows = ground truth) with an LDS-histogram
 HIP kernel on the device the predictions live on -- the reference first copies both int64 maps to
@@ -195,6 +196,116 @@ class UncertaintyAccuracyAggregator:
         if save_path is not None:
             fig.savefig(save_path, dpi=dpi, bbox_inches="tight")
         return fig, ax
+
+
+class UncertaintyPerClassAggregator:
+    """Per-class uncertainty samples across batches (reference evaluator.py:191-281) kept on the DEVICE: ``update`` is one stable
+    group-by-class pass (``csrc/metrics.hip``) instead of two device-to-host copies and C boolean masks on the host.  Without a cap
+    nothing synchronises until the lists are read; with ``max_per_class`` the numpy-seeded (approximate) reservoir makes the same
+    draws, in the same order, as the reference (C sample counts cross to the host per batch).  ``_values`` / ``_seen_counts`` keep
+    the reference's meaning (``tester.py:356-357,648-649`` caches them); the plotting helpers are the reference's, run on host copies."""
+
+    def __init__(self, num_classes: int, max_per_class=None, seed: int = 0):
+        self.num_classes = int(num_classes)
+        self.max_per_class = max_per_class
+        self.rng = np.random.default_rng(seed)
+        self.reset()
+
+    def reset(self):
+        self._lists = [torch.empty(0, dtype=torch.float32) for _ in range(self.num_classes)]
+        self._seen = [0 for _ in range(self.num_classes)]
+        self._pending = []                                   # (grouped values, counts) of batches not yet split per class
+
+    def _absorb(self, grouped: torch.Tensor, cnt) -> None:
+        off = 0
+        for c in range(self.num_classes):
+            k = int(cnt[c])
+            if k == 0:
+                continue
+            vals = grouped[off:off + k]
+            off += k
+            self._seen[c] += k
+            cur = self._lists[c]
+            if cur.device != vals.device:
+                cur = cur.to(vals.device)
+            cap = self.max_per_class
+            if cap is None:
+                self._lists[c] = torch.cat([cur, vals])
+            elif cur.numel() < cap:
+                take = min(cap - cur.numel(), k)
+                if take < k:
+                    vals = vals[torch.from_numpy(self.rng.choice(k, size=take, replace=False)).to(vals.device)]
+                self._lists[c] = torch.cat([cur, vals])
+            else:
+                accept = self.rng.random(k) < min(1.0, float(cap) / float(self._seen[c] + 1e-9))
+                if accept.any():
+                    chosen = vals[torch.from_numpy(accept).to(vals.device)]
+                    slots = torch.from_numpy(self.rng.choice(cap, size=int(chosen.numel()), replace=False)).to(vals.device)
+                    cur[slots] = chosen
+                    self._lists[c] = cur
+
+    def _flush(self) -> None:
+        if self._pending:
+            counts = torch.stack([c for _, c in self._pending]).cpu().tolist()      # one copy for all deferred batches
+            pending, self._pending = self._pending, []
+            for (grouped, _), cnt in zip(pending, counts):
+                self._absorb(grouped, cnt)
+
+    @property
+    def _values(self):
+        self._flush()
+        return self._lists
+
+    @_values.setter
+    def _values(self, vals):
+        self._pending = []
+        self._lists = list(vals)
+
+    @property
+    def _seen_counts(self):
+        self._flush()
+        return self._seen
+
+    @_seen_counts.setter
+    def _seen_counts(self, counts):
+        self._flush()
+        self._seen = list(counts)
+
+    @torch.no_grad()
+    def update(self, labels: torch.Tensor, uncertainty: torch.Tensor):
+        assert labels.shape == uncertainty.shape, "labels and uncertainty must have same shape"
+        if not uncertainty.is_cuda:
+            raise RuntimeError("UncertaintyPerClassAggregator.update: the uncertainty map must be on the GPU (no CPU fallback)")
+        if labels.numel() == 0:
+            return
+        lab = labels.detach().to(device=uncertainty.device, dtype=torch.int64).reshape(-1).contiguous()
+        unc = uncertainty.detach().to(torch.float32).reshape(-1).contiguous()
+        grouped, counts = ops.group_by_class(lab, unc, self.num_classes)
+        if self.max_per_class is None:
+            self._pending.append((grouped, counts))
+        else:
+            self._flush()
+            self._absorb(grouped, counts.cpu().tolist())
+
+    def as_dataframe(self, class_names: list, ignore_ids=()):
+        """Long DataFrame [class_id, class, uncertainty] (evaluator.py:264-281)."""
+        import pandas as pd
+        skip = set(ignore_ids)
+        rows = [pd.DataFrame({"class_id": c, "class": class_names[c], "uncertainty": v.cpu().numpy()})
+                for c, v in enumerate(self._values) if c not in skip and v.numel() > 0]
+        return pd.concat(rows, ignore_index=True) if rows else pd.DataFrame(columns=["class_id", "class", "uncertainty"])
+
+    def __getattr__(self, name):
+        # plot_boxplot / plot_ridgeline / plot_ridgeline_fast: the reference's matplotlib code, bound to a host copy of the samples
+        if name.startswith("plot_"):
+            from semanticlidarunc_amd._shadow import shadowed_module
+            ref = getattr(shadowed_module(__name__, __file__), "UncertaintyPerClassAggregator", None)
+            if ref is not None and hasattr(ref, name):
+                host = ref.__new__(ref)
+                host.num_classes, host.max_per_class, host.rng = self.num_classes, self.max_per_class, self.rng
+                host._values, host._seen_counts = [v.cpu() for v in self._values], list(self._seen_counts)
+                return getattr(host, name)
+        raise AttributeError(f"{type(self).__name__!s} has no attribute {name!r}")
 
 
 # drop-in mode (this file shadows the reference's module of the same import path): names it does not define come from there

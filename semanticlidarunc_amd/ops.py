@@ -807,6 +807,23 @@ def dirichlet_loss_bwd(alpha: torch.Tensor, labels: torch.Tensor, kind: str, par
     return g
 
 
+def group_by_class(labels: torch.Tensor, values: torch.Tensor, num_classes: int):
+    """labels int64 [n], values fp32 [n] (device) -> (grouped fp32 [n]: class 0's samples, then class 1's, ... in scan order; the first
+    counts.sum() entries are meaningful), counts int64 [C] (device)."""
+    _req(labels, "labels", torch.int64)
+    _req(values, "values")
+    if labels.dim() != 1 or labels.shape != values.shape or labels.numel() == 0:
+        raise RuntimeError(f"group_by_class: equally long non-empty 1-D labels / values expected, got {tuple(labels.shape)} / {tuple(values.shape)}")
+    n = labels.numel()
+    lib = _lib.load()
+    ws = torch.empty(lib.slu_group_by_class_workspace_bytes(n), dtype=torch.uint8, device=labels.device)
+    out = torch.empty(n, dtype=torch.float32, device=labels.device)
+    counts = torch.empty(int(num_classes), dtype=torch.int64, device=labels.device)
+    check(lib.slu_group_by_class(labels.data_ptr(), values.data_ptr(), n, int(num_classes), out.data_ptr(), counts.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), _stream()), "slu_group_by_class")
+    return out, counts
+
+
 def _c_params(params):
     import ctypes as C
     vals = [float(v) for v in params]

@@ -203,6 +203,21 @@ def test_tversky_golden():
     assert float(olosses.tversky(logits, torch.full((2, 8, 64), 255), 20, "logits")) == float(g["loss:all_ignored"]) == 0.0
 
 
+def test_per_class_samples_golden():
+    """oracle.metrics.PerClassSamples against the lists the reference's UncertaintyPerClassAggregator held (unlimited and capped)."""
+    g = golden("per_class_uncertainty_3x2x16x64")
+    for tag, cap in (("all", None), ("cap300", 300)):
+        agg = ometrics.PerClassSamples(6, cap, seed=5)
+        for b in range(3):
+            agg.update(g["labels"][b], g["uncertainty"][b])
+        assert np.array_equal(np.concatenate(agg.values), g["values:" + tag])
+        assert [v.size for v in agg.values] == g["sizes:" + tag].tolist() and agg.seen == g["seen:" + tag].tolist()
+    # known answer: scan order inside a class, labels outside [0, C) dropped
+    agg = ometrics.PerClassSamples(2)
+    agg.update(np.array([[1, 0, 5], [1, 1, 0]]), np.array([[0.1, 0.2, 0.3], [0.4, 0.5, 0.6]], dtype=np.float32))
+    assert np.allclose(agg.values[0], [0.2, 0.6]) and np.allclose(agg.values[1], [0.1, 0.4, 0.5]) and agg.seen == [2, 3]
+
+
 def test_dirichlet_losses_golden():
     """oracle.dirichlet.loss_* against the reference's Dirichlet loss modules (values and gradients)."""
     from oracle import dirichlet as odir

@@ -344,6 +344,27 @@ def main():
     save("tversky_2x20x8x64", **out)
     print("  oracle.losses.tversky == reference TverskyLoss (value and gradient identical)")
 
+    # ---------------- per-class uncertainty samples (models/evaluator.py UncertaintyPerClassAggregator) ----------------
+    from models.evaluator import UncertaintyPerClassAggregator as RefPC      # reference
+    g = torch.Generator().manual_seed(909)
+    pc_lab = torch.randint(0, 6, (3, 2, 16, 64), generator=g)                  # three batches
+    pc_lab[torch.rand(3, 2, 16, 64, generator=g) < 0.5] = 1                    # one dominant class, so a cap of 300 bites early
+    pc_unc = torch.rand(3, 2, 16, 64, generator=g)
+    out = {"labels": pc_lab.numpy(), "uncertainty": pc_unc.numpy()}
+    for tag, cap in (("all", None), ("cap300", 300)):
+        ref_pc, my_pc = RefPC(6, max_per_class=cap, seed=5), ometrics.PerClassSamples(6, cap, seed=5)
+        for b in range(3):
+            ref_pc.update(pc_lab[b], pc_unc[b])
+            my_pc.update(pc_lab[b].numpy(), pc_unc[b].numpy())
+        for c in range(6):
+            assert np.array_equal(ref_pc._values[c].numpy(), my_pc.values[c]), (tag, c)
+        assert list(ref_pc._seen_counts) == my_pc.seen
+        out["values:" + tag] = np.concatenate([v.numpy() for v in ref_pc._values])
+        out["sizes:" + tag] = np.asarray([v.numel() for v in ref_pc._values], dtype=np.int64)
+        out["seen:" + tag] = np.asarray(ref_pc._seen_counts, dtype=np.int64)
+    save("per_class_uncertainty_3x2x16x64", **out)
+    print("  oracle.metrics.PerClassSamples == reference UncertaintyPerClassAggregator (lists and seen counts identical)")
+
     # ---------------- per-pixel Dirichlet losses (losses/dirichlet_losses.py, losses/regularizers.py) ----------------
     from losses import dirichlet_losses as ref_dl, regularizers as ref_reg     # reference
     from oracle import dirichlet as odir2
