@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
   const int abase = (wm * MB) * a_stride + lane;
   const int bbase = hh * REC + (wn * RPW) * LW + jj;                    // + (rr + dy)*LW + cb*32 + dx
 
-  struct TilePos { int x0, y0, n; };
+  struct TilePos { int x0, y0, n, i0, i1, i2; };      // i_s: the image of source s that output image n reads (once per tile, not per chunk)
   auto decode = [&](int t) {
     TilePos p;
     const int tx = t % a.tiles_x;
@@ -246,8 +246,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
     p.x0 = tx * TW;
     p.y0 = (t % a.tiles_y) * TH;
     p.n = t / a.tiles_y;
+    p.i0 = a.src[0].nb ? p.n % a.src[0].nb : p.n;
+    p.i1 = (a.nsrc > 1 && a.src[1].nb) ? p.n % a.src[1].nb : p.n;
+    p.i2 = (a.nsrc > 2 && a.src[2].nb) ? p.n % a.src[2].nb : p.n;
     return p;
   };
+  static_assert(SLU_MAX_SRC == 3, "TilePos carries one image index per source");
   // Per-lane description of the input-tile pieces this wave copies (the same for every chunk and tile): piece i covers
   // records [64 (i NWAVE + wave), +64) of the [2][LH][LW] tile image; pc_rc = row | col << 8 | block << 16 | inside << 17.
   int pc_rc[NIB], pc_off[NIB];
@@ -273,9 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
   int st_x0 = 0, st_y0 = 0, st_q = 0;
   uint4 *st_db = s_b, *st_da = s_a;
   auto stage_begin = [&](const TilePos& tp, int q, int buf) {
-    int img[SLU_MAX_SRC];
-#pragma unroll
-    for (int s = 0; s < SLU_MAX_SRC; ++s) img[s] = (s < a.nsrc && a.src[s].nb) ? tp.n % a.src[s].nb : tp.n;
+    const int img[SLU_MAX_SRC] = {tp.i0, tp.i1, tp.i2};
     // wave-uniform: the two channel blocks of this K-step, as byte addresses of the record at tile-image position (0, 0)
     const long long org = (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD);
     st_live0 = 2 * q < a.Gin;

@@ -6,6 +6,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from semanticlidarunc_amd import _lib  # noqa: E402
+
+if os.environ.get("SLU_LIB_PATH"):          # A/B runs of two builds on the same box
+    _lib.LIB_PATH = os.path.abspath(os.environ["SLU_LIB_PATH"])
 from semanticlidarunc_amd import h8  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
