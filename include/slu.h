@@ -378,6 +378,11 @@ size_t slu_spherical_projection_workspace_bytes(int N, int H, int W);
 int slu_spherical_projection(const double* pc, int N, int C, int H, int W, int use_data_theta_range, double theta_min, double theta_max,
                              void* workspace, size_t workspace_bytes, float* img, double* theta_range_out, slu_stream_t stream);
 
+/* ---- surface normals of the projected image (dataset/utils.py:30-58 build_normal_xyz; inference_ouster.py:70) ------
+ * xyz: fp32 [H][W][channels >= 3] (x, y, z first); normals: fp32 [H][W][3] = -(d xyz/d col x d xyz/d row) / (|.| + 1e-10) with the 3x3
+ * Scharr derivatives of OpenCV (cv2.Scharr(..., scale = 1 / norm_factor), BORDER_REFLECT_101). */
+int slu_build_normals(const float* xyz, int H, int W, int channels, float norm_factor, float* normals, slu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

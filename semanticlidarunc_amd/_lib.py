@@ -137,6 +137,7 @@ SIGNATURES = {
                                          c_stream]),
     "slu_dirichlet_loss_bwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int64, c_f32p, c_f32p,
                                          c_stream]),
+    "slu_build_normals": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_stream]),
     "slu_group_by_class_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "slu_group_by_class": (C.c_int, [c_i64p, c_f32p, C.c_longlong, C.c_int, c_f32p, c_i64p, C.c_void_p, C.c_size_t, c_stream]),
     "slu_dirichlet_loss_fwd_ex": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_int, C.c_int64,

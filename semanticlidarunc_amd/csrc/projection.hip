@@ -147,3 +147,59 @@ extern "C" int slu_spherical_projection(const double* pc, int N, int C, int H, i
     hipLaunchKernelGGL(theta_range_kernel, dim3(1), dim3(1), 0, st, mm, use_data_theta_range, theta_min, theta_max, theta_range_out);
   SLU_CHECK_LAUNCH();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Surface normals of a staggered range image (dataset/utils.py:30-58 build_normal_xyz, called by every
+// dataloader and by inference_ouster.py:70).  Per coordinate plane two 3x3 Scharr derivatives -- OpenCV's cv2.Scharr
+// (opencv-python 4.11.0.86 in docker/requirements.txt: taps [-1 0 1] x [3 10 3], border BORDER_REFLECT_101, result times
+// `scale`) -- then n = -(d/dcol x d/drow) per pixel, divided by (|n| + 1e-10).  One lane per pixel; the 27 neighbours come
+// through L1/L2 (a 64x2048x3 image is 1.5 MB).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int reflect101(int i, int n) {       // gfedcb|abcdefgh|gfedcba ; n == 1: always 0
+  if (n == 1) return 0;
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ xyz, int H, int W, int stride_px, float scale,
+                                                      float* __restrict__ out) {
+  // no FMA contraction here: where the two tangent vectors are parallel the reference's a*b - b*a is exactly 0 (-> the zero
+  // normal), while fma(a, b, -(b*a)) leaves the rounding error of one product, which the normalisation would blow up to length 1
+#pragma clang fp contract(off)
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W), ym = reflect101(y - 1, H), yp = reflect101(y + 1, H);
+  float dcol[3], drow[3];                                        // d/dx (along a row) and d/dy (along a column) of the X, Y, Z planes
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    auto at = [&](int yy, int xx) { return xyz[((size_t)yy * W + xx) * stride_px + c]; };
+    // separable, rows first, in float32 (the order OpenCV's FilterEngine uses)
+    // (symmetric taps summed first, like OpenCV's symmetric small-kernel filters; `scale` sits in the smoothing taps there)
+    const float r_m = at(ym, xp) - at(ym, xm), r_0 = at(y, xp) - at(y, xm), r_p = at(yp, xp) - at(yp, xm);
+    dcol[c] = (10.0f * scale) * r_0 + (3.0f * scale) * (r_m + r_p);
+    const float s_m = (10.0f * scale) * at(ym, x) + (3.0f * scale) * (at(ym, xm) + at(ym, xp));
+    const float s_p = (10.0f * scale) * at(yp, x) + (3.0f * scale) * (at(yp, xm) + at(yp, xp));
+    drow[c] = s_p - s_m;
+  }
+  // Sxx = dcol[0], Sxy = drow[0], Syx = dcol[1], Syy = drow[1], Szx = dcol[2], Szy = drow[2]
+  float n0 = -(dcol[1] * drow[2] - dcol[2] * drow[1]);
+  float n1 = -(dcol[2] * drow[0] - drow[2] * dcol[0]);
+  float n2 = -(dcol[0] * drow[1] - dcol[1] * drow[0]);
+  const float len = sqrtf(n0 * n0 + n1 * n1 + n2 * n2) + 1e-10f;
+  float* o = out + ((size_t)y * W + x) * 3;
+  o[0] = n0 / len;
+  o[1] = n1 / len;
+  o[2] = n2 / len;
+}
+
+}  // namespace
+
+extern "C" int slu_build_normals(const float* xyz, int H, int W, int channels, float norm_factor, float* normals, slu_stream_t stream) {
+  if (!xyz || !normals || H <= 0 || W <= 0 || channels < 3 || !(norm_factor > 0.0f)) return SLU_EINVAL;
+  if (H > 65535) return SLU_EUNSUPPORTED;
+  hipLaunchKernelGGL(normals_kernel, dim3((W + 255) / 256, H), dim3(256), 0, slu_stream(stream), xyz, H, W, channels, 1.0f / norm_factor, normals);
+  SLU_CHECK_LAUNCH();
+}

@@ -1,7 +1,7 @@
-"""Drop-in for ``spherical_projection`` / ``to_deflection_coordinates`` of the reference's ``dataset/utils.py`` (:61-67, :288-349):
-same arguments and return tuple ``(pj_img, alpha, (theta_min, theta_max), (phi_min, phi_max))`` with numpy arrays, the
-projection itself (angles, bin search, nearest-point selection, gather) running in HIP kernels (``csrc/projection.hip``).
-Every other helper of the reference module (plots, normals, rotations) is re-exported from the shadowed file in drop-in mode."""
+"""Drop-in for ``spherical_projection`` / ``to_deflection_coordinates`` / ``build_normal_xyz`` of the reference's ``dataset/utils.py``
+(:61-67, :288-349, :30-58): same arguments and return values (numpy arrays), the projection itself (angles, bin search,
+nearest-point selection, gather) and the Scharr / cross-product normals running in HIP kernels (``csrc/projection.hip``).
+Every other helper of the reference module (plots, rotations) is re-exported from the shadowed file in drop-in mode."""
 from __future__ import annotations
 
 import numpy as np
@@ -42,6 +42,20 @@ def spherical_projection(pc, height=64, width=2048, theta_range=None, th=1.0, so
     bins_w = np.linspace(phi_min, phi_max, width)[::-1]
     alpha = np.sqrt(np.square(np.stack(width * [bins_h], axis=-1)) + np.square(np.stack(height * [bins_w], axis=0)))
     return img.cpu().numpy(), alpha, (theta_min, theta_max), (phi_min, phi_max)
+
+
+def build_normal_xyz(xyz, norm_factor=0.25, ksize=3, device="cuda"):
+    """(h, w, 3) staggered point image -> (h, w, 3) float32 unit normals (reference :30-58; ``ksize`` is unused there as well).
+    A numpy image returns numpy (the reference's contract); a GPU tensor returns a GPU tensor without leaving the device."""
+    if torch.utils.data.get_worker_info() is not None:
+        if _shadowed is not None:                     # forked DataLoader worker: the reference's cv2 code, as for the projection
+            return _shadowed.build_normal_xyz(xyz, norm_factor, ksize)
+        raise RuntimeError("build_normal_xyz: the HIP kernel cannot run inside a DataLoader worker process; compute the normals in the "
+                           "main process (num_workers=0) or keep the reference's dataset/utils.py on sys.path")
+    as_tensor = isinstance(xyz, torch.Tensor)
+    t = xyz if as_tensor else torch.from_numpy(np.ascontiguousarray(xyz))
+    out = ops.build_normals(t.to(device=device if not t.is_cuda else t.device, dtype=torch.float32).contiguous(), norm_factor)
+    return out if as_tensor else out.cpu().numpy()
 
 
 # drop-in mode (this file shadows the reference's module of the same import path): names it does not define come from there

@@ -807,6 +807,17 @@ def dirichlet_loss_bwd(alpha: torch.Tensor, labels: torch.Tensor, kind: str, par
     return g
 
 
+def build_normals(xyz: torch.Tensor, norm_factor: float = 0.25):
+    """xyz fp32 [H, W, C >= 3] on the GPU -> unit normals fp32 [H, W, 3] (Scharr derivatives, cross product, normalisation)."""
+    _req(xyz, "xyz")
+    if xyz.dim() != 3 or xyz.shape[2] < 3:
+        raise RuntimeError(f"xyz: expected [H, W, C >= 3], got {tuple(xyz.shape)}")
+    h, w, c = xyz.shape
+    out = torch.empty((h, w, 3), dtype=torch.float32, device=xyz.device)
+    check(_lib.load().slu_build_normals(xyz.data_ptr(), h, w, c, float(norm_factor), out.data_ptr(), _stream()), "slu_build_normals")
+    return out
+
+
 def group_by_class(labels: torch.Tensor, values: torch.Tensor, num_classes: int):
     """labels int64 [n], values fp32 [n] (device) -> (grouped fp32 [n]: class 0's samples, then class 1's, ... in scan order; the first
     counts.sum() entries are meaningful), counts int64 [C] (device)."""

@@ -257,6 +257,26 @@ def test_dirichlet_losses_golden():
     assert float(odir.loss_wrong_low_evidence(wrong[..., 1:], yw[..., 1:], None, 0.0, 0.1, 0.0)) == 0.0
 
 
+def test_normals_known_answers():
+    """oracle.normals (Scharr restated from OpenCV's definition; parity unpinned, see its header): planes, a sphere, the border rule."""
+    from oracle import normals as onorm
+    h, w = 12, 40
+    j, i = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    # Scharr of a ramp: (3 + 10 + 3) * 2 * slope * scale in the interior, 0 on the reflected border
+    assert np.allclose(onorm.scharr(2.0 * j, 1, 0, 4.0)[1:-1, 1:-1], 16 * 2 * 2.0 * 4.0) and np.all(onorm.scharr(2.0 * j, 1, 0)[:, 0] == 0)
+    assert np.all(onorm.scharr(2.0 * j, 0, 1) == 0) and np.allclose(onorm.scharr(3.0 * i, 0, 1)[1:-1], 16 * 2 * 3.0)
+    # a plane z = 0.1 col + 0.2 row: n = -(d/dcol x d/drow) = (0.1, 0.2, -1) / |.|
+    n = onorm.build_normal_xyz(np.dstack([j, i, 0.1 * j + 0.2 * i]))
+    want = np.array([0.1, 0.2, -1.0]) / np.linalg.norm([0.1, 0.2, -1.0])
+    assert n.dtype == np.float32 and np.allclose(n[1:-1, 1:-1], want, atol=1e-6) and np.all(n[0, 0] == 0)
+    # a sphere sampled on an (elevation, azimuth) grid like a range image: the normal is radial up to sign and discretisation
+    el, az = np.meshgrid(np.linspace(0.4, -0.4, 32), np.linspace(np.pi, -np.pi, 256, endpoint=False), indexing="ij")
+    p = 10.0 * np.dstack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+    n = onorm.build_normal_xyz(p)[1:-1, 1:-1]
+    radial = (p / 10.0)[1:-1, 1:-1]
+    assert np.abs(np.abs((n * radial).sum(-1)) - 1.0).max() < 1e-3 and np.allclose(np.linalg.norm(n, axis=-1), 1.0, atol=1e-5)
+
+
 def test_spherical_projection_golden_and_known_answers():
     """oracle.projection against the image the reference's dataset.utils.spherical_projection produced."""
     from oracle import projection as oproj

@@ -18,6 +18,8 @@ LAYERS = [  # (cin parts, cout, k, dil, pad, H, W, resid)
     ([32], 32, 3, 1, 1, 64, 2048, False), ([32], 32, 3, 2, 2, 64, 2048, True), ([64], 64, 3, 2, 2, 64, 2048, False),
     ([64], 64, 2, 2, 1, 64, 2048, False), ([64, 64, 64], 64, 1, 1, 0, 64, 2048, True), ([32], 32, 1, 1, 0, 64, 2048, False),
     ([128], 128, 3, 2, 2, 32, 1024, False), ([256], 256, 3, 2, 2, 16, 512, False), ([128, 128, 128], 128, 1, 1, 0, 32, 1024, True),
+    ([32], 32, 2, 2, 1, 64, 2048, False), ([128], 128, 2, 2, 1, 32, 1024, False), ([256], 256, 2, 2, 1, 16, 512, False),
+    ([128], 128, 3, 1, 1, 32, 1024, False), ([256], 256, 3, 1, 1, 8, 256, False),
 ]
 sel = os.environ.get("SLU_LAYERS")
 for li, (parts, cout, k, dil, pad, H, W, res) in enumerate(LAYERS):
