@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 12
+#define SLU_ABI_VERSION 13
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -287,6 +287,27 @@ int slu_avgpool3s2_h8(const void* x, const float* scale, void* y, int N, int in_
  * x: h8 with Gin blocks at HxW; y: h8 with ceil(2 Gin / 8) blocks at 2Hx2W; scales fp32 [N][8 Gin] / [N][2 Gin] or NULL */
 int slu_pixel_shuffle_h8(const void* x, const float* scale_in, const float* scale_out, void* y, int N, int Gin, int H, int W,
                          slu_stream_t stream);
+
+/* Fused tail of a SalsaNext block on the h8 path (ResBlock.conv4 + conv5, SalsaNext.py:59-68; UpBlock.conv3 + conv4, :157-167):
+ *   a3  = bnA_a * actA(conv2x2_dil2_pad1(a2) + biasA) + bnA_b          (kept on chip, rounded to fp16 like the stored tensor would be)
+ *   out = [resid +] bnB_a * actB(conv1x1(cat(a1, a2, a3)) + biasB) + bnB_b
+ * a1, a2, resid, out: h8 [N][C/8][H][W][8]; w2x2 = slu_pack_conv_weight_h8 of [C][C][2][2]; w1x1 = the same of [C][3C][1][1].
+ * C in {32, 64} (slu_conv_tail_h8_supported); anything else: run the two layers through slu_conv2d_h8_fwd. */
+typedef struct slu_conv_tail_h8_desc {   /* HOST struct */
+  const void *a1, *a2;
+  int32_t N, H, W, C;
+  const void *w2x2, *w1x1;
+  const float *biasA, *bnA_a, *bnA_b;   /* [C] fp32 or NULL */
+  int32_t hasactA;
+  float slopeA;
+  const float *biasB, *bnB_a, *bnB_b;
+  int32_t hasactB;
+  float slopeB;
+  const void* resid;
+  void* out;
+} slu_conv_tail_h8_desc;
+int slu_conv_tail_h8_supported(int C, int H, int W);
+int slu_conv_tail_h8_fwd(const slu_conv_tail_h8_desc* desc, slu_stream_t stream);
 
 /* ---- Dirichlet head (the reference's default loss path, configs/SemanticKitti_default.yaml:10) ---------------
  * alpha = 1 + softplus(scale / T) * softmax(shape) + eps   (probability_helper.py:89-105; trainer.py:533-535 splits the C+1

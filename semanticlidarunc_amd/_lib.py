@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -56,6 +56,19 @@ class ConvH8Desc(C.Structure):
         ("bn_a", C.c_void_p), ("bn_b", C.c_void_p),
         ("resid", C.c_void_p), ("out", C.c_void_p),
         ("out_f32_nchw", C.c_int32),
+    ]
+
+
+class ConvTailH8Desc(C.Structure):
+    _fields_ = [
+        ("a1", C.c_void_p), ("a2", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("w2x2", C.c_void_p), ("w1x1", C.c_void_p),
+        ("biasA", C.c_void_p), ("bnA_a", C.c_void_p), ("bnA_b", C.c_void_p),
+        ("hasactA", C.c_int32), ("slopeA", C.c_float),
+        ("biasB", C.c_void_p), ("bnB_a", C.c_void_p), ("bnB_b", C.c_void_p),
+        ("hasactB", C.c_int32), ("slopeB", C.c_float),
+        ("resid", C.c_void_p), ("out", C.c_void_p),
     ]
 
 
@@ -137,6 +150,8 @@ SIGNATURES = {
                                          c_stream]),
     "slu_dirichlet_loss_bwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int64, c_f32p, c_f32p,
                                          c_stream]),
+    "slu_conv_tail_h8_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "slu_conv_tail_h8_fwd": (C.c_int, [C.POINTER(ConvTailH8Desc), c_stream]),
     "slu_build_normals": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_stream]),
     "slu_group_by_class_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "slu_group_by_class": (C.c_int, [c_i64p, c_f32p, C.c_longlong, C.c_int, c_f32p, c_i64p, C.c_void_p, C.c_size_t, c_stream]),

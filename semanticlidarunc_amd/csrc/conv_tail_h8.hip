@@ -1,0 +1,327 @@
+// Fused tail of a SalsaNext block on the half-precision ("h8") path:
+//
+//     a3  = bnA * leaky(conv2x2_dil2(a2) + biasA) + bnA_b                (ResBlock.conv4 / UpBlock.conv3, SalsaNext.py:59-62,157-160)
+//     out = [resid +] bnB * leaky(conv1x1(cat(a1, a2, a3)) + biasB) + bnB_b   (ResBlock.conv5 / UpBlock.conv4, :64-68,162-167)
+//
+// Unfused these are two kernels moving 7 tensor passes (read a2, write a3; read a1, a2, a3, resid, write out); here a3 never
+// leaves the CU: 4 passes (a1, a2, resid, out), both layers HBM-bound at full resolution.  Structure = the persistent LDS-DMA
+// kernel of conv2d_h8.hip (round-robin tiles, one K-step = 16 channels per chunk, double-buffered, the next tile's first chunk
+// in flight across the epilogues):
+//   chunks 0 .. nks-1      : a2 tile (halo 1) -> 4 dilated taps into acc3  +  the centre tap (1x1 over a2) into acc_out
+//   chunks nks .. 2 nks-1  : a1 tile          -> the centre tap (1x1 over a1) into acc_out
+//   epilogue A             : acc3 -> bias, LeakyReLU, BN -> fp16 -> LDS image of a3 in B-operand layout [block][row][64]
+//   stage 3                : 1x1 over a3 from LDS (its weights stay resident in LDS) into acc_out
+//   epilogue B             : acc_out -> bias, LeakyReLU, BN, + resid -> h8 store
+// C = 32 MB channels (MB = 1: the full-resolution up-block; MB = 2: ResBlock 1 / the half-resolution up-block), one wave row
+// per RPW output rows, 8 waves.  The a3 image takes C * TH * 128 B = 64 KB for (C, TH) = (32, 16) and (64, 8).
+#include "slu_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ uint4 g_zero_rec_t;      // source of every out-of-image record of an LDS-DMA copy (never written)
+__device__ uint4 g_trash_rec_t;     // where lanes outside the image store
+
+#define SLU_GLDS16_T(gsrc, ldst_wave_base)                                                                \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),                 \
+                                   (__attribute__((address_space(3))) void*)(ldst_wave_base), 16, 0, 0)
+
+struct TailArgs {
+  const uint4 *a1, *a2;        // h8 [N][G][H][W]
+  const uint4 *w2, *w1;        // packed 2x2 weights [MB][nks][4][64]; packed 1x1 weights over 3 C inputs [MB][3 nks][1][64]
+  const float *biasA, *bnA_a, *bnA_b, *biasB, *bnB_a, *bnB_b;
+  float slopeA, slopeB;        // 1 = no activation
+  const uint2* resid;          // h8 or nullptr
+  uint2* out;
+  int N, H, W, G;              // G = C / 8 channel blocks
+  int tiles_x, tiles_y;
+};
+
+template <int MB, int WN, int RPW>
+__global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
+  constexpr int NWAVE = WN, T = 4, PAD = 1, DIL = 2;
+  constexpr int C = 32 * MB, NKS = 2 * MB;
+  constexpr int TW = 64, TH = WN * RPW, NB = 2 * RPW;
+  constexpr int LW = TW + 2 * PAD, LH = TH + 2 * PAD, REC = LH * LW;
+  constexpr int NREC_B = 2 * REC, NBLK_B = (NREC_B + 63) / 64, NB_ALLOC = NBLK_B * 64;
+  constexpr int NBLK_A = MB * (T + 1), NREC_A = NBLK_A * 64;       // per chunk: 4 tap fragments + 1 centre fragment per channel block
+  constexpr int NIB = (NBLK_B + NWAVE - 1) / NWAVE, NIA = (NBLK_A + NWAVE - 1) / NWAVE;
+  constexpr int NST = MB * NB * 4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_epi = reinterpret_cast<float*>(smem);                    // A: bias | bn_a | bn_b ; B: bias | bn_a | bn_b   (6 C floats)
+  uint4* s_b = reinterpret_cast<uint4*>(s_epi + 6 * C);             // [2][NB_ALLOC] input tiles
+  uint4* s_a = s_b + 2 * NB_ALLOC;                                  // [2][NREC_A] weight fragments of a chunk
+  uint4* s_w3 = s_a + 2 * NREC_A;                                   // [MB][NKS][64] resident: 1x1 weights over a3
+  uint4* s_a3 = s_w3 + MB * NKS * 64;                               // [C / 8][TH][64] the a3 tile
+
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int hh = lane >> 5, jj = lane & 31;
+  const size_t HW = (size_t)a.H * a.W;
+
+  int t_beg, t_end, t_step;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
+    t_step = nwg;
+    t_beg = w;
+    t_end = w < nt ? w + (int)((nt - w + nwg - 1) / nwg) * nwg : w;
+  }
+  if (t_beg >= t_end) return;
+
+  if (tid < C) {
+    s_epi[tid] = a.biasA ? a.biasA[tid] : 0.0f;
+    s_epi[C + tid] = a.bnA_a ? a.bnA_a[tid] : 1.0f;
+    s_epi[2 * C + tid] = a.bnA_a ? a.bnA_b[tid] : 0.0f;
+    s_epi[3 * C + tid] = a.biasB ? a.biasB[tid] : 0.0f;
+    s_epi[4 * C + tid] = a.bnB_a ? a.bnB_a[tid] : 1.0f;
+    s_epi[5 * C + tid] = a.bnB_a ? a.bnB_b[tid] : 0.0f;
+  }
+  for (int blk = wn; blk < MB * NKS; blk += NWAVE) {                 // resident 1x1 weights of the a3 third: K-steps 2 NKS .. 3 NKS - 1
+    const int m = blk / NKS, k = blk - m * NKS;
+    SLU_GLDS16_T(a.w1 + ((size_t)m * 3 * NKS + 2 * NKS + k) * 64 + lane, s_w3 + blk * 64);
+  }
+
+  struct TilePos { int x0, y0, n; };
+  auto decode = [&](int t) {
+    TilePos p;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    p.x0 = tx * TW;
+    p.y0 = (t % a.tiles_y) * TH;
+    p.n = t / a.tiles_y;
+    return p;
+  };
+  int pc_rc[NIB], pc_off[NIB];
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    const int e = (i * NWAVE + wn) * 64 + lane;
+    const int g2 = e / REC, rem = e - g2 * REC, r = rem / LW, c = rem - r * LW;
+    pc_rc[i] = r | (c << 8) | ((g2 & 1) << 16) | ((e < NREC_B ? 1 : 0) << 17);
+    pc_off[i] = r * a.W + c;
+  }
+  // chunk c of a tile: c < NKS: K-step c of a2 (+ its 2x2 and 1x1 weight fragments); else K-step c - NKS of a1 (+ its 1x1 fragments)
+  auto stage = [&](const TilePos& tp, int c, int buf) {
+    const bool second = c >= NKS;
+    const int q = second ? c - NKS : c;
+    const uint4* src = second ? a.a1 : a.a2;
+    const uintptr_t base0 = reinterpret_cast<uintptr_t>(src) +
+                            16 * ((long long)(((size_t)tp.n * a.G + 2 * q) * HW) + (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD));
+    const uintptr_t base1 = base0 + 16 * (long long)HW;
+    uint4* db = s_b + buf * NB_ALLOC;
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int blk = i * NWAVE + wn;
+      if (NBLK_B % NWAVE == 0 || blk < NBLK_B) {
+        const int rc = pc_rc[i];
+        const int gy = tp.y0 - PAD + (rc & 255), gx = tp.x0 - PAD + ((rc >> 8) & 255);
+        const bool ok = (rc >> 17) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const uintptr_t p = ok ? (((rc >> 16) & 1) ? base1 : base0) + 16 * (long long)pc_off[i] : reinterpret_cast<uintptr_t>(&g_zero_rec_t);
+        SLU_GLDS16_T(reinterpret_cast<const uint4*>(p), db + blk * 64);
+      }
+    }
+    uint4* da = s_a + buf * NREC_A;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int blk = i * NWAVE + wn;                                  // = m * (T + 1) + f ; f < T: tap fragment, f == T: centre (1x1) fragment
+      if (NBLK_A % NWAVE == 0 || blk < NBLK_A) {
+        const int m = blk / (T + 1), f = blk - m * (T + 1);
+        if (f < T) {
+          if (!second) SLU_GLDS16_T(a.w2 + (((size_t)m * NKS + q) * T + f) * 64 + lane, da + blk * 64);      // a1 chunks have no 2x2 taps
+        } else {
+          SLU_GLDS16_T(a.w1 + ((size_t)m * 3 * NKS + (second ? q : NKS + q)) * 64 + lane, da + blk * 64);     // cat order (a1, a2, a3)
+        }
+      }
+    }
+  };
+
+  const int bbase = hh * REC + (wn * RPW) * LW + jj;
+  TilePos cur = decode(t_beg), nxt = cur;
+  stage(cur, 0, 0);
+  int buf = 0;
+  const float2v slA = {a.slopeA, a.slopeA}, slB = {a.slopeB, a.slopeB};
+  const float4* se4 = reinterpret_cast<const float4*>(s_epi);
+
+  for (int tile = t_beg; tile < t_end; tile += t_step) {
+    f32x16 acc3[MB][NB], acco[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc3[i][b][r] = 0.0f; acco[i][b][r] = 0.0f; }
+
+    for (int c = 0; c < 2 * NKS; ++c) {
+      // the chunk has landed; at a tile's first chunk only the NST stores of the previous tile's epilogue are younger than its DMA
+      if (c == 0 && tile != t_beg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST < 63 ? NST : 63) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (c + 1 < 2 * NKS) {
+        stage(cur, c + 1, buf ^ 1);
+      } else if (tile + t_step < t_end) {
+        nxt = decode(tile + t_step);
+        stage(nxt, 0, buf ^ 1);
+      }
+      const uint4* sb = s_b + buf * NB_ALLOC + bbase;
+      const uint4* sa = s_a + buf * NREC_A + lane;
+      if (c < NKS) {
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+          const int dy = (tap >> 1) * DIL, dx = (tap & 1) * DIL;
+          half8 af[MB];
+#pragma unroll
+          for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, sa[(i * (T + 1) + tap) * 64]);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const half8 bf = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc3[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acc3[i][b], 0, 0, 0);
+          }
+        }
+      }
+      {      // centre tap: the 1x1 conv over this K-step of a2 / a1
+        half8 af[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, sa[(i * (T + 1) + T) * 64]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const half8 bf = __builtin_bit_cast(half8, sb[((b >> 1) + PAD) * LW + (b & 1) * 32 + PAD]);
+#pragma unroll
+          for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acco[i][b], 0, 0, 0);
+        }
+      }
+      buf ^= 1;
+    }
+
+    // ---- epilogue A: a3 tile -> LDS (fp16, the rounding the unfused path applies when it stores a3) ----
+    {
+      uint2* s3 = reinterpret_cast<uint2*>(s_a3);
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int row = wn * RPW + (b >> 1), px = (b & 1) * 32 + jj;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c4 = (i * 32 + 8 * q) / 4 + hh;
+            const float4 bi = se4[c4], ba = se4[C / 4 + c4], bb = se4[2 * C / 4 + c4];
+            float2v t0 = {acc3[i][b][4 * q], acc3[i][b][4 * q + 1]}, t1 = {acc3[i][b][4 * q + 2], acc3[i][b][4 * q + 3]};
+            t0 += float2v{bi.x, bi.y};
+            t1 += float2v{bi.z, bi.w};
+            t0 = __builtin_elementwise_max(t0, t0 * slA);
+            t1 = __builtin_elementwise_max(t1, t1 * slA);
+            t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
+            t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
+            s3[((((i * 4 + q) * TH + row) * 64 + px) << 1) + hh] =
+                make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v)), __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v)));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ---- stage 3: 1x1 over a3 (B operands from the LDS tile; K-step k = channel blocks 2k, 2k+1) ----
+#pragma unroll
+    for (int k = 0; k < NKS; ++k) {
+      half8 af[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, s_w3[(i * NKS + k) * 64 + lane]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const half8 bf = __builtin_bit_cast(half8, s_a3[((2 * k + hh) * TH + wn * RPW + (b >> 1)) * 64 + (b & 1) * 32 + jj]);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acco[i][b], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue B: every lane issues its 4 stores per accumulator tile (counted vmcnt above) ----
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
+        const bool ok = gy < a.H && gx < a.W;
+        const size_t idx0 = ok ? ((((size_t)cur.n * a.G + i * 4) * HW + (size_t)gy * a.W + gx) << 1) + hh : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c4 = (i * 32 + 8 * q) / 4 + hh;
+          const float4 bi = se4[3 * C / 4 + c4], ba = se4[4 * C / 4 + c4], bb = se4[5 * C / 4 + c4];
+          float2v t0 = {acco[i][b][4 * q], acco[i][b][4 * q + 1]}, t1 = {acco[i][b][4 * q + 2], acco[i][b][4 * q + 3]};
+          t0 += float2v{bi.x, bi.y};
+          t1 += float2v{bi.z, bi.w};
+          t0 = __builtin_elementwise_max(t0, t0 * slB);
+          t1 = __builtin_elementwise_max(t1, t1 * slB);
+          t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
+          t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
+          const size_t idx = idx0 + (size_t)q * HW * 2;
+          if (a.resid) {
+            const uint2 r = *(ok ? a.resid + idx : reinterpret_cast<const uint2*>(&g_zero_rec_t));
+            t0 += __builtin_convertvector(__builtin_bit_cast(half2v, r.x), float2v);
+            t1 += __builtin_convertvector(__builtin_bit_cast(half2v, r.y), float2v);
+          }
+          *(ok ? a.out + idx : reinterpret_cast<uint2*>(&g_trash_rec_t)) =
+              make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v)), __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    cur = nxt;
+  }
+}
+
+template <int MB, int WN, int RPW>
+int launch_tail(TailArgs& a, hipStream_t st) {
+  constexpr int TH = WN * RPW, C = 32 * MB, NKS = 2 * MB;
+  constexpr size_t nb_alloc = (size_t)((2 * (TH + 2) * 66 + 63) / 64) * 64;
+  constexpr size_t lds = (size_t)6 * C * 4 + 2 * nb_alloc * 16 + (size_t)2 * MB * 5 * 64 * 16 + (size_t)MB * NKS * 64 * 16 + (size_t)(C / 8) * TH * 64 * 16;
+  static_assert(lds <= 160 * 1024, "tile does not fit in LDS");
+  a.tiles_x = (a.W + 63) / 64;
+  a.tiles_y = (a.H + TH - 1) / TH;
+  const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
+  if (nt <= 0 || nt > 0x7fffffffLL) return SLU_EUNSUPPORTED;
+  long long gx = 256;                                                 // one 8-wave workgroup per CU (LDS)
+  if (gx > nt) gx = nt;
+  auto kern = tail_h8_kernel<MB, WN, RPW>;
+  static bool attr_set = false;                                       // benign race: the call is idempotent
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SLU_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(64 * WN), lds, st, a);
+  SLU_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" int slu_conv_tail_h8_supported(int C, int H, int W) { return (C == 32 || C == 64) && H > 0 && W > 0 ? 1 : 0; }
+
+extern "C" int slu_conv_tail_h8_fwd(const slu_conv_tail_h8_desc* d, slu_stream_t stream) {
+  if (!d || !d->a1 || !d->a2 || !d->w2x2 || !d->w1x1 || !d->out || d->N <= 0 || d->H <= 0 || d->W <= 0) return SLU_EINVAL;
+  if (((uintptr_t)d->a1 | (uintptr_t)d->a2 | (uintptr_t)d->out | (uintptr_t)d->resid | (uintptr_t)d->w2x2 | (uintptr_t)d->w1x1) & 15) return SLU_EINVAL;
+  if ((d->bnA_a == nullptr) != (d->bnA_b == nullptr) || (d->bnB_a == nullptr) != (d->bnB_b == nullptr)) return SLU_EINVAL;
+  if (!slu_conv_tail_h8_supported(d->C, d->H, d->W)) return SLU_EUNSUPPORTED;
+  if (d->hasactA && !(d->slopeA >= 0.0f && d->slopeA <= 1.0f)) return SLU_EINVAL;      // LeakyReLU as max(t, slope t)
+  if (d->hasactB && !(d->slopeB >= 0.0f && d->slopeB <= 1.0f)) return SLU_EINVAL;
+  TailArgs a{};
+  a.a1 = reinterpret_cast<const uint4*>(d->a1);
+  a.a2 = reinterpret_cast<const uint4*>(d->a2);
+  a.w2 = reinterpret_cast<const uint4*>(d->w2x2);
+  a.w1 = reinterpret_cast<const uint4*>(d->w1x1);
+  a.biasA = d->biasA; a.bnA_a = d->bnA_a; a.bnA_b = d->bnA_b;
+  a.biasB = d->biasB; a.bnB_a = d->bnB_a; a.bnB_b = d->bnB_b;
+  a.slopeA = d->hasactA ? d->slopeA : 1.0f;
+  a.slopeB = d->hasactB ? d->slopeB : 1.0f;
+  a.resid = reinterpret_cast<const uint2*>(d->resid);
+  a.out = reinterpret_cast<uint2*>(d->out);
+  a.N = d->N; a.H = d->H; a.W = d->W; a.G = d->C / 8;
+  hipStream_t st = slu_stream(stream);
+  return d->C == 32 ? launch_tail<1, 8, 2>(a, st) : launch_tail<2, 8, 1>(a, st);
+}

@@ -149,6 +149,64 @@ def conv2d_h8(srcs: Sequence[H8Source], wpack: torch.Tensor, cin: int, cout: int
     return out
 
 
+def conv_tail_supported(channels: int, h: int, w: int) -> bool:
+    return bool(_lib.load().slu_conv_tail_h8_supported(int(channels), int(h), int(w)))
+
+
+def conv_tail_h8(a1: torch.Tensor, a2: torch.Tensor, w2x2: torch.Tensor, w1x1: torch.Tensor,
+                 bias_a: Optional[torch.Tensor], slope_a: Optional[float], bn_a: Optional[tuple],
+                 bias_b: Optional[torch.Tensor], slope_b: Optional[float], bn_b: Optional[tuple],
+                 resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The fused tail of a SalsaNext block (slu_conv_tail_h8_fwd):
+        a3  = bn_a(leaky(conv2x2_dil2(a2) + bias_a));   out = [resid +] bn_b(leaky(conv1x1(cat(a1, a2, a3)) + bias_b))
+    a1 / a2 / resid: h8 [N, C/8, H, W, 8]; w2x2 / w1x1: pack_conv_weight_h8 of [C, C, 2, 2] / [C, 3C, 1, 1]; bn_*: (scale, shift) or None."""
+    lib = _lib.load()
+    _req_h8(a1, "a1")
+    _req_h8(a2, "a2")
+    if a1.shape != a2.shape:
+        raise RuntimeError(f"conv_tail_h8: a1 {tuple(a1.shape)} != a2 {tuple(a2.shape)}")
+    n, g, h, w, _ = a1.shape
+    c = 8 * g
+    if not conv_tail_supported(c, h, w):
+        raise RuntimeError(f"conv_tail_h8: C={c} is not covered by the fused kernel (use two conv2d_h8 calls)")
+    _req(w2x2, "w2x2", torch.uint8)
+    _req(w1x1, "w1x1", torch.uint8)
+    if w2x2.numel() != lib.slu_packed_weight_bytes_h8(c, c, 2) or w1x1.numel() != lib.slu_packed_weight_bytes_h8(c, 3 * c, 1):
+        raise RuntimeError("conv_tail_h8: packed weight sizes do not match C")
+    d = _lib.ConvTailH8Desc()
+    for name, t in (("bias_a", bias_a), ("bias_b", bias_b)) + tuple((f"bn_{k}[{i}]", v) for k, pair in (("a", bn_a), ("b", bn_b)) if pair is not None
+                                                                       for i, v in enumerate(pair)):
+        if t is not None:
+            _req(t, name)
+            if t.numel() != c:
+                raise RuntimeError(f"{name}: expected {c} elements, got {t.numel()}")
+    if resid is not None:
+        _req_h8(resid, "resid")
+        if resid.shape != a1.shape:
+            raise RuntimeError(f"resid: expected {tuple(a1.shape)}, got {tuple(resid.shape)}")
+    out = torch.empty_like(a1)
+    d.a1, d.a2, d.N, d.H, d.W, d.C = a1.data_ptr(), a2.data_ptr(), n, h, w, c
+    d.w2x2, d.w1x1 = w2x2.data_ptr(), w1x1.data_ptr()
+    d.biasA, d.bnA_a, d.bnA_b = _ptr(bias_a), _ptr(None if bn_a is None else bn_a[0]), _ptr(None if bn_a is None else bn_a[1])
+    d.biasB, d.bnB_a, d.bnB_b = _ptr(bias_b), _ptr(None if bn_b is None else bn_b[0]), _ptr(None if bn_b is None else bn_b[1])
+    d.hasactA, d.slopeA = (0, 0.0) if slope_a is None else (1, float(slope_a))
+    d.hasactB, d.slopeB = (0, 0.0) if slope_b is None else (1, float(slope_b))
+    d.resid, d.out = _ptr(resid), out.data_ptr()
+    if ops.TIMING is None:
+        check(lib.slu_conv_tail_h8_fwd(C.byref(d), _stream()), "slu_conv_tail_h8_fwd")
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.slu_conv_tail_h8_fwd(C.byref(d), _stream()), "slu_conv_tail_h8_fwd")
+    e1.record()
+    # the layer-granular convention of SURVEY 8(d): both convs read their inputs and write their outputs once
+    flops = 2.0 * c * c * (4 + 3) * n * h * w
+    nbytes = n * h * w * 2.0 * (c + c + 3 * c + c) + 2.0 * c * c * (4 + 3)
+    ops.TIMING.append((f"tail_h8_kernel<{c // 32}, 8, {2 if c == 32 else 1}>", flops, nbytes, e0, e1))
+    ops.TIMING_TAGS.append(f"N{n} {c}->{c} k2d2 + {3 * c}->{c} k1 fused {h}x{w}")
+    return out
+
+
 def avgpool3s2_h8(x: torch.Tensor, scale: Optional[torch.Tensor] = None, n_out: Optional[int] = None) -> torch.Tensor:
     """AvgPool2d(3, 2, 1) of x[n % B] * scale[n] for n < n_out (n_out = B unless x is shared by stacked MC passes)."""
     _req_h8(x, "x")

@@ -38,6 +38,8 @@ _CONV_PRECISION = os.environ.get("SLU_CONV_PRECISION", "fp32")
 # relative product error; activations are O(1)).  Data- and weight-gradient kernels are always exact fp32: gradients fall
 # below fp16's range.
 _TRAIN_CONV_PRECISION = os.environ.get("SLU_TRAIN_CONV_PRECISION", "fp32")
+# half-precision inference: run a block's 2x2-dilated conv and its concat 1x1 conv as one launch (0: two launches; A/B switch)
+_FUSE_TAIL = os.environ.get("SLU_FUSE_TAIL", "1") != "0"
 
 
 def set_train_conv_precision(precision: str) -> None:
@@ -100,6 +102,36 @@ class _FusedBlock(nn.Module):
                             conv.out_channels, conv.kernel_size[0], conv.dilation[0], conv.padding[0],
                             bias=None if conv.bias is None else conv.bias.detach(), slope=_SLOPE if act else None,
                             bn_a=bn_a, bn_b=bn_b, resid=resid, out_f32_nchw=out_f32)
+
+    def _prepared(self, conv: nn.Conv2d) -> _Prepared:
+        cache: Dict[str, _Prepared] = self.__dict__.setdefault("_prep", {})
+        p = cache.get(str(id(conv)))
+        if p is None:
+            p = cache[str(id(conv))] = _Prepared()
+        return p
+
+    def _run_tail(self, conv_a: nn.Conv2d, bn_a, conv_b: nn.Conv2d, bn_b, a1, a2, resid=None):
+        """The last two layers of a block, `conv_b(cat(a1, a2, conv_a(a2)))`, each followed by LeakyReLU and eval BatchNorm.
+        Half-precision inference with 32 / 64 channels: one fused launch that keeps conv_a's output on chip (csrc/conv_tail_h8.hip);
+        otherwise the two layers one after the other."""
+        c = conv_a.out_channels
+        if (_FUSE_TAIL and a1.dtype == torch.float16 and a1.dim() == 5 and conv_a.kernel_size == (2, 2) and conv_a.dilation == (2, 2)
+                and conv_b.kernel_size == (1, 1) and conv_b.in_channels == 3 * c and conv_b.out_channels == c
+                and h8.conv_tail_supported(c, a1.shape[2], a1.shape[3])):
+            packs, folded = [], []
+            for conv, bn in ((conv_a, bn_a), (conv_b, bn_b)):
+                p = self._prepared(conv)
+                wkey = _tkey(conv.weight)
+                if p.key8 != wkey:
+                    p.wpack8 = h8.pack_conv_weight_h8(conv.weight.detach().contiguous())
+                    p.key8 = wkey
+                packs.append(p.wpack8)
+                fa, fb = self._folded_bn(p, bn)
+                folded.append(None if fa is None else (fa, fb))
+            return h8.conv_tail_h8(a1, a2, packs[0], packs[1], None if conv_a.bias is None else conv_a.bias.detach(), _SLOPE, folded[0],
+                                   None if conv_b.bias is None else conv_b.bias.detach(), _SLOPE, folded[1], resid=resid)
+        a3 = self._run(conv_a, bn_a, [ConvSource(a2)])
+        return self._run(conv_b, bn_b, [ConvSource(a1), ConvSource(a2), ConvSource(a3)], resid=resid)
 
     def _run(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], srcs, resid=None, act=True, out_f32=False):
         cache: Dict[str, _Prepared] = self.__dict__.setdefault("_prep", {})
@@ -199,8 +231,7 @@ class ResBlock(_FusedBlock):
         shortcut = self._run(self.conv1, None, src)
         a1 = self._run(self.conv2, self.bn1, src)
         a2 = self._run(self.conv3, self.bn2, [ConvSource(a1)])
-        a3 = self._run(self.conv4, self.bn3, [ConvSource(a2)])
-        return self._run(self.conv5, self.bn4, [ConvSource(a1), ConvSource(a2), ConvSource(a3)], resid=shortcut)
+        return self._run_tail(self.conv4, self.bn3, self.conv5, self.bn4, a1, a2, resid=shortcut)
 
     def forward(self, x, _scales=None, _name=""):
         """pooling: (pooled, full_res);  else: (full_res, deferred dropout multiplier or None)."""
@@ -257,8 +288,7 @@ class UpBlock(_FusedBlock):
                 sx = sx.contiguous()
             e1 = self._run(self.conv1, self.bn1, [ConvSource(x, sx, True), ConvSource(skip, ss, False, skip_nbatch)])
         e2 = self._run(self.conv2, self.bn2, [ConvSource(e1)])
-        e3 = self._run(self.conv3, self.bn3, [ConvSource(e2)])
-        out = self._run(self.conv4, self.bn4, [ConvSource(e1), ConvSource(e2), ConvSource(e3)])
+        out = self._run_tail(self.conv3, self.bn3, self.conv4, self.bn4, e1, e2)
         s3 = None
         if self.drop_out:
             s3 = _draw(self.dropout3, n, self.out_filters, dev, _scales, _name + ".dropout3")

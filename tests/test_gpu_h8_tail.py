@@ -1,0 +1,60 @@
+"""GPU: the fused tail of a SalsaNext block on the h8 path (2x2 dilated conv kept on chip + the 1x1 conv over the concatenation)
+against (a) the same two layers through the unfused h8 kernels -- same fp16 operands, same fp16 rounding of the intermediate, only the
+fp32 accumulation order of the 1x1 differs -- and (b) a plain torch fp32 evaluation on the fp16-rounded inputs.
+Bars: 2e-3 of the output scale vs the unfused path (one fp16 ulp of an O(1) output is 1e-3), 1e-2 vs fp32 torch."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from semanticlidarunc_amd import h8
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(cuda, c, n, hh, ww, resid, seed, slope_a=0.01, slope_b=0.01, bn=True):
+    g = torch.Generator(device=cuda).manual_seed(seed)
+    a1 = torch.randn(n, c, hh, ww, device=cuda, generator=g)
+    a2 = torch.randn(n, c, hh, ww, device=cuda, generator=g)
+    r = torch.randn(n, c, hh, ww, device=cuda, generator=g) if resid else None
+    w2 = torch.randn(c, c, 2, 2, device=cuda, generator=g) / (4 * c) ** 0.5
+    w1 = torch.randn(c, 3 * c, 1, 1, device=cuda, generator=g) / (3 * c) ** 0.5
+    ba, bb = torch.randn(c, device=cuda, generator=g) * 0.1, torch.randn(c, device=cuda, generator=g) * 0.1
+    bna = (torch.rand(c, device=cuda, generator=g) + 0.5, torch.randn(c, device=cuda, generator=g) * 0.1) if bn else None
+    bnb = (torch.rand(c, device=cuda, generator=g) + 0.5, torch.randn(c, device=cuda, generator=g) * 0.1) if bn else None
+    h1, h2, hr = h8.to_h8(a1), h8.to_h8(a2), (None if r is None else h8.to_h8(r))
+    p2, p1 = h8.pack_conv_weight_h8(w2), h8.pack_conv_weight_h8(w1)
+    fused = h8.from_h8(h8.conv_tail_h8(h1, h2, p2, p1, ba, slope_a, bna, bb, slope_b, bnb, resid=hr), c)
+    # unfused h8
+    kw = lambda pair: dict(bn_a=None if pair is None else pair[0], bn_b=None if pair is None else pair[1])
+    h3 = h8.conv2d_h8([h8.H8Source(h2)], p2, c, c, 2, 2, 1, bias=ba, slope=slope_a, **kw(bna))
+    unf = h8.from_h8(h8.conv2d_h8([h8.H8Source(h1), h8.H8Source(h2), h8.H8Source(h3)], p1, 3 * c, c, 1, 1, 0, bias=bb, slope=slope_b,
+                                  resid=hr, **kw(bnb)), c)
+    # torch fp32 on the fp16-rounded operands
+    q = lambda t: t.half().float()
+    act = lambda t, s: t if s is None else F.leaky_relu(t, s)
+    aff = lambda t, pair: t if pair is None else t * pair[0].view(1, -1, 1, 1) + pair[1].view(1, -1, 1, 1)
+    a3 = q(aff(act(F.conv2d(q(a2), q(w2), ba, dilation=2, padding=1), slope_a), bna))
+    ref = aff(act(F.conv2d(torch.cat([q(a1), q(a2), a3], 1), q(w1), bb), slope_b), bnb)
+    if r is not None:
+        ref = ref + q(r)
+    scale = float(ref.abs().max())
+    assert float((fused - unf).abs().max()) <= 2e-3 * scale, (c, n, hh, ww, float((fused - unf).abs().max()), scale)
+    assert float((fused - ref).abs().max()) <= 1e-2 * scale, (c, n, hh, ww, float((fused - ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize("c", [32, 64])
+def test_tail_matches_unfused_and_fp32(cuda, c):
+    _case(cuda, c, 2, 64, 256, True, 1)
+    _case(cuda, c, 3, 16, 64, False, 2)                                    # one tile column, several images
+    _case(cuda, c, 1, 19, 150, True, 3)                                    # ragged: partial tiles in both directions
+    _case(cuda, c, 2, 5, 37, False, 4, slope_a=None, slope_b=None, bn=False)   # no activation, no BN, tiny image
+    _case(cuda, c, 70, 8, 64, True, 5)                                     # more tiles than one round of workgroups... per image 1
+
+
+def test_tail_many_tiles_and_argument_checks(cuda):
+    _case(cuda, 64, 6, 64, 2048, True, 6)                                  # 6 x 8 x 32 = 1536 tiles: six rounds of the persistent grid
+    _case(cuda, 32, 5, 64, 2048, False, 7)
+    assert h8.conv_tail_supported(32, 64, 2048) and h8.conv_tail_supported(64, 32, 1024) and not h8.conv_tail_supported(128, 32, 1024)
+    x = h8.to_h8(torch.zeros(1, 128, 8, 64, device=cuda))
+    with pytest.raises(RuntimeError):
+        h8.conv_tail_h8(x, x, torch.zeros(1, dtype=torch.uint8, device=cuda), torch.zeros(1, dtype=torch.uint8, device=cuda), None, None, None, None, None, None)
