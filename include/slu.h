@@ -292,7 +292,7 @@ int slu_pixel_shuffle_h8(const void* x, const float* scale_in, const float* scal
  *   a3  = bnA_a * actA(conv2x2_dil2_pad1(a2) + biasA) + bnA_b          (kept on chip, rounded to fp16 like the stored tensor would be)
  *   out = [resid +] bnB_a * actB(conv1x1(cat(a1, a2, a3)) + biasB) + bnB_b
  * a1, a2, resid, out: h8 [N][C/8][H][W][8]; w2x2 = slu_pack_conv_weight_h8 of [C][C][2][2]; w1x1 = the same of [C][3C][1][1].
- * C in {32, 64} (slu_conv_tail_h8_supported); anything else: run the two layers through slu_conv2d_h8_fwd. */
+ * C in {32, 64, 128} (slu_conv_tail_h8_supported); anything else: run the two layers through slu_conv2d_h8_fwd. */
 typedef struct slu_conv_tail_h8_desc {   /* HOST struct */
   const void *a1, *a2;
   int32_t N, H, W, C;

@@ -12,8 +12,9 @@
 //   epilogue A             : acc3 -> bias, LeakyReLU, BN -> fp16 -> LDS image of a3 in B-operand layout [block][row][64]
 //   stage 3                : 1x1 over a3 from LDS (its weights stay resident in LDS) into acc_out
 //   epilogue B             : acc_out -> bias, LeakyReLU, BN, + resid -> h8 store
-// C = 32 MB channels (MB = 1: the full-resolution up-block; MB = 2: ResBlock 1 / the half-resolution up-block), one wave row
-// per RPW output rows, 8 waves.  The a3 image takes C * TH * 128 B = 64 KB for (C, TH) = (32, 16) and (64, 8).
+// C = 32 MB WM channels, 8 waves = WM x WN, a wave owns MB channel blocks and RPW output rows: (C, TH) = (32, 16), (64, 8), (128, 4)
+// -- the a3 image takes C * TH * 128 B = 64 KB in each.  W3RES: the 1x1 weights over a3 stay resident in LDS (C <= 64); otherwise
+// they stream through the chunk pipeline as NKS more (weights-only) chunks, for which the LDS has no room at C = 128.
 #include "slu_common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -41,14 +42,15 @@ struct TailArgs {
   int tiles_x, tiles_y;
 };
 
-template <int MB, int WN, int RPW>
-__global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
-  constexpr int NWAVE = WN, T = 4, PAD = 1, DIL = 2;
-  constexpr int C = 32 * MB, NKS = 2 * MB;
+template <int MB, int WM, int WN, int RPW, bool W3RES>
+__global__ __launch_bounds__(64 * WM * WN, 2) void tail_h8_kernel(const TailArgs a) {
+  constexpr int NWAVE = WM * WN, T = 4, PAD = 1, DIL = 2;
+  constexpr int MBLK = MB * WM, C = 32 * MBLK, NKS = 2 * MBLK;
+  constexpr int NCH = W3RES ? 2 * NKS : 3 * NKS;                       // chunks per tile
   constexpr int TW = 64, TH = WN * RPW, NB = 2 * RPW;
   constexpr int LW = TW + 2 * PAD, LH = TH + 2 * PAD, REC = LH * LW;
   constexpr int NREC_B = 2 * REC, NBLK_B = (NREC_B + 63) / 64, NB_ALLOC = NBLK_B * 64;
-  constexpr int NBLK_A = MB * (T + 1), NREC_A = NBLK_A * 64;       // per chunk: 4 tap fragments + 1 centre fragment per channel block
+  constexpr int NBLK_A = MBLK * (T + 1), NREC_A = NBLK_A * 64;     // per chunk: 4 tap fragments + 1 centre fragment per channel block
   constexpr int NIB = (NBLK_B + NWAVE - 1) / NWAVE, NIA = (NBLK_A + NWAVE - 1) / NWAVE;
   constexpr int NST = MB * NB * 4;
 
@@ -56,10 +58,10 @@ __global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
   float* s_epi = reinterpret_cast<float*>(smem);                    // A: bias | bn_a | bn_b ; B: bias | bn_a | bn_b   (6 C floats)
   uint4* s_b = reinterpret_cast<uint4*>(s_epi + 6 * C);             // [2][NB_ALLOC] input tiles
   uint4* s_a = s_b + 2 * NB_ALLOC;                                  // [2][NREC_A] weight fragments of a chunk
-  uint4* s_w3 = s_a + 2 * NREC_A;                                   // [MB][NKS][64] resident: 1x1 weights over a3
-  uint4* s_a3 = s_w3 + MB * NKS * 64;                               // [C / 8][TH][64] the a3 tile
+  uint4* s_w3 = s_a + 2 * NREC_A;                                   // W3RES: [MBLK][NKS][64] resident 1x1 weights over a3
+  uint4* s_a3 = s_w3 + (W3RES ? MBLK * NKS * 64 : 0);               // [C / 8][TH][64] the a3 tile
 
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
   const int hh = lane >> 5, jj = lane & 31;
   const size_t HW = (size_t)a.H * a.W;
 
@@ -82,9 +84,11 @@ __global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
     s_epi[4 * C + tid] = a.bnB_a ? a.bnB_a[tid] : 1.0f;
     s_epi[5 * C + tid] = a.bnB_a ? a.bnB_b[tid] : 0.0f;
   }
-  for (int blk = wn; blk < MB * NKS; blk += NWAVE) {                 // resident 1x1 weights of the a3 third: K-steps 2 NKS .. 3 NKS - 1
-    const int m = blk / NKS, k = blk - m * NKS;
-    SLU_GLDS16_T(a.w1 + ((size_t)m * 3 * NKS + 2 * NKS + k) * 64 + lane, s_w3 + blk * 64);
+  if constexpr (W3RES) {
+    for (int blk = wave; blk < MBLK * NKS; blk += NWAVE) {             // resident 1x1 weights of the a3 third: K-steps 2 NKS .. 3 NKS - 1
+      const int m = blk / NKS, k = blk - m * NKS;
+      SLU_GLDS16_T(a.w1 + ((size_t)m * 3 * NKS + 2 * NKS + k) * 64 + lane, s_w3 + blk * 64);
+    }
   }
 
   struct TilePos { int x0, y0, n; };
@@ -100,15 +104,16 @@ __global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
   int pc_rc[NIB], pc_off[NIB];
 #pragma unroll
   for (int i = 0; i < NIB; ++i) {
-    const int e = (i * NWAVE + wn) * 64 + lane;
+    const int e = (i * NWAVE + wave) * 64 + lane;
     const int g2 = e / REC, rem = e - g2 * REC, r = rem / LW, c = rem - r * LW;
     pc_rc[i] = r | (c << 8) | ((g2 & 1) << 16) | ((e < NREC_B ? 1 : 0) << 17);
     pc_off[i] = r * a.W + c;
   }
-  // chunk c of a tile: c < NKS: K-step c of a2 (+ its 2x2 and 1x1 weight fragments); else K-step c - NKS of a1 (+ its 1x1 fragments)
+  // chunk c of a tile: c < NKS: K-step c of a2 (+ its 2x2 and 1x1 weight fragments); c < 2 NKS: K-step c - NKS of a1 (+ its 1x1
+  // fragments); else (streamed w3): only the 1x1 fragments of K-step c - 2 NKS of a3
   auto stage = [&](const TilePos& tp, int c, int buf) {
-    const bool second = c >= NKS;
-    const int q = second ? c - NKS : c;
+    const bool second = c >= NKS, third = c >= 2 * NKS;
+    const int q = third ? c - 2 * NKS : (second ? c - NKS : c);
     const uint4* src = second ? a.a1 : a.a2;
     const uintptr_t base0 = reinterpret_cast<uintptr_t>(src) +
                             16 * ((long long)(((size_t)tp.n * a.G + 2 * q) * HW) + (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD));
@@ -116,8 +121,8 @@ __global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
     uint4* db = s_b + buf * NB_ALLOC;
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
-      const int blk = i * NWAVE + wn;
-      if (NBLK_B % NWAVE == 0 || blk < NBLK_B) {
+      const int blk = i * NWAVE + wave;
+      if (!third && (NBLK_B % NWAVE == 0 || blk < NBLK_B)) {
         const int rc = pc_rc[i];
         const int gy = tp.y0 - PAD + (rc & 255), gx = tp.x0 - PAD + ((rc >> 8) & 255);
         const bool ok = (rc >> 17) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
@@ -128,19 +133,19 @@ __global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
     uint4* da = s_a + buf * NREC_A;
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
-      const int blk = i * NWAVE + wn;                                  // = m * (T + 1) + f ; f < T: tap fragment, f == T: centre (1x1) fragment
+      const int blk = i * NWAVE + wave;                                // = m * (T + 1) + f ; f < T: tap fragment, f == T: centre (1x1) fragment
       if (NBLK_A % NWAVE == 0 || blk < NBLK_A) {
         const int m = blk / (T + 1), f = blk - m * (T + 1);
         if (f < T) {
           if (!second) SLU_GLDS16_T(a.w2 + (((size_t)m * NKS + q) * T + f) * 64 + lane, da + blk * 64);      // a1 chunks have no 2x2 taps
         } else {
-          SLU_GLDS16_T(a.w1 + ((size_t)m * 3 * NKS + (second ? q : NKS + q)) * 64 + lane, da + blk * 64);     // cat order (a1, a2, a3)
+          SLU_GLDS16_T(a.w1 + ((size_t)m * 3 * NKS + (third ? 2 * NKS + q : (second ? q : NKS + q))) * 64 + lane, da + blk * 64);   // cat order (a1, a2, a3)
         }
       }
     }
   };
 
-  const int bbase = hh * REC + (wn * RPW) * LW + jj;
+  const int bbase = hh * REC + (wn * RPW) * LW + jj;      // wn: the wave's row group; wm: its channel-block group
   TilePos cur = decode(t_beg), nxt = cur;
   stage(cur, 0, 0);
   int buf = 0;
@@ -156,21 +161,59 @@ __global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc3[i][b][r] = 0.0f; acco[i][b][r] = 0.0f; }
 
-    for (int c = 0; c < 2 * NKS; ++c) {
+    // epilogue A: a3 tile -> LDS (fp16, the rounding the unfused path applies when it stores a3)
+    auto a3_to_lds = [&]() {
+      uint2* s3 = reinterpret_cast<uint2*>(s_a3);
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int row = wn * RPW + (b >> 1), px = (b & 1) * 32 + jj, ml = wm * MB + i;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c4 = (ml * 32 + 8 * q) / 4 + hh;
+            const float4 bi = se4[c4], ba = se4[C / 4 + c4], bb = se4[2 * C / 4 + c4];
+            float2v t0 = {acc3[i][b][4 * q], acc3[i][b][4 * q + 1]}, t1 = {acc3[i][b][4 * q + 2], acc3[i][b][4 * q + 3]};
+            t0 += float2v{bi.x, bi.y};
+            t1 += float2v{bi.z, bi.w};
+            t0 = __builtin_elementwise_max(t0, t0 * slA);
+            t1 = __builtin_elementwise_max(t1, t1 * slA);
+            t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
+            t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
+            s3[((((ml * 4 + q) * TH + row) * 64 + px) << 1) + hh] =
+                make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v)), __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v)));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // one K-step of the 1x1 over a3: B operands from the LDS tile (channel blocks 2k, 2k+1), weight fragments from `wf`
+    auto a3_step = [&](int k, const uint4* wf, int wstride) {
+      half8 af[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, wf[i * wstride]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const half8 bf = __builtin_bit_cast(half8, s_a3[((2 * k + hh) * TH + wn * RPW + (b >> 1)) * 64 + (b & 1) * 32 + jj]);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acco[i][b], 0, 0, 0);
+      }
+    };
+
+    for (int c = 0; c < NCH; ++c) {
       // the chunk has landed; at a tile's first chunk only the NST stores of the previous tile's epilogue are younger than its DMA
       if (c == 0 && tile != t_beg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST < 63 ? NST : 63) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (c + 1 < 2 * NKS) {
+      if (c + 1 < NCH) {
         stage(cur, c + 1, buf ^ 1);
       } else if (tile + t_step < t_end) {
         nxt = decode(tile + t_step);
         stage(nxt, 0, buf ^ 1);
       }
       const uint4* sb = s_b + buf * NB_ALLOC + bbase;
-      const uint4* sa = s_a + buf * NREC_A + lane;
+      const uint4* sa = s_a + buf * NREC_A + (wm * MB) * (T + 1) * 64 + lane;
       if (c < NKS) {
 #pragma unroll
         for (int tap = 0; tap < T; ++tap) {
@@ -186,7 +229,7 @@ __global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
           }
         }
       }
-      {      // centre tap: the 1x1 conv over this K-step of a2 / a1
+      if (W3RES || c < 2 * NKS) {      // centre tap: the 1x1 conv over this K-step of a2 / a1
         half8 af[MB];
 #pragma unroll
         for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, sa[(i * (T + 1) + T) * 64]);
@@ -196,51 +239,20 @@ __global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
 #pragma unroll
           for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acco[i][b], 0, 0, 0);
         }
+      } else {
+        a3_step(c - 2 * NKS, sa + T * 64, (T + 1) * 64);               // streamed w3: this chunk carried only the centre fragments
       }
+      if (!W3RES && c == 2 * NKS - 1) a3_to_lds();                     // visible to every wave after the next chunk's barrier
       buf ^= 1;
     }
 
-    // ---- epilogue A: a3 tile -> LDS (fp16, the rounding the unfused path applies when it stores a3) ----
-    {
-      uint2* s3 = reinterpret_cast<uint2*>(s_a3);
+    if constexpr (W3RES) {
+      a3_to_lds();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int row = wn * RPW + (b >> 1), px = (b & 1) * 32 + jj;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c4 = (i * 32 + 8 * q) / 4 + hh;
-            const float4 bi = se4[c4], ba = se4[C / 4 + c4], bb = se4[2 * C / 4 + c4];
-            float2v t0 = {acc3[i][b][4 * q], acc3[i][b][4 * q + 1]}, t1 = {acc3[i][b][4 * q + 2], acc3[i][b][4 * q + 3]};
-            t0 += float2v{bi.x, bi.y};
-            t1 += float2v{bi.z, bi.w};
-            t0 = __builtin_elementwise_max(t0, t0 * slA);
-            t1 = __builtin_elementwise_max(t1, t1 * slA);
-            t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
-            t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
-            s3[((((i * 4 + q) * TH + row) * 64 + px) << 1) + hh] =
-                make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v)), __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v)));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    // ---- stage 3: 1x1 over a3 (B operands from the LDS tile; K-step k = channel blocks 2k, 2k+1) ----
-#pragma unroll
-    for (int k = 0; k < NKS; ++k) {
-      half8 af[MB];
-#pragma unroll
-      for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, s_w3[(i * NKS + k) * 64 + lane]);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const half8 bf = __builtin_bit_cast(half8, s_a3[((2 * k + hh) * TH + wn * RPW + (b >> 1)) * 64 + (b & 1) * 32 + jj]);
-#pragma unroll
-        for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acco[i][b], 0, 0, 0);
-      }
+      for (int k = 0; k < NKS; ++k) a3_step(k, s_w3 + ((wm * MB) * NKS + k) * 64 + lane, NKS * 64);
     }
 
     // ---- epilogue B: every lane issues its 4 stores per accumulator tile (counted vmcnt above) ----
@@ -248,12 +260,12 @@ __global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
+        const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj, ml = wm * MB + i;
         const bool ok = gy < a.H && gx < a.W;
-        const size_t idx0 = ok ? ((((size_t)cur.n * a.G + i * 4) * HW + (size_t)gy * a.W + gx) << 1) + hh : 0;
+        const size_t idx0 = ok ? ((((size_t)cur.n * a.G + ml * 4) * HW + (size_t)gy * a.W + gx) << 1) + hh : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int c4 = (i * 32 + 8 * q) / 4 + hh;
+          const int c4 = (ml * 32 + 8 * q) / 4 + hh;
           const float4 bi = se4[3 * C / 4 + c4], ba = se4[4 * C / 4 + c4], bb = se4[5 * C / 4 + c4];
           float2v t0 = {acco[i][b][4 * q], acco[i][b][4 * q + 1]}, t1 = {acco[i][b][4 * q + 2], acco[i][b][4 * q + 3]};
           t0 += float2v{bi.x, bi.y};
@@ -277,11 +289,12 @@ __global__ __launch_bounds__(64 * WN, 2) void tail_h8_kernel(const TailArgs a) {
   }
 }
 
-template <int MB, int WN, int RPW>
+template <int MB, int WM, int WN, int RPW, bool W3RES>
 int launch_tail(TailArgs& a, hipStream_t st) {
-  constexpr int TH = WN * RPW, C = 32 * MB, NKS = 2 * MB;
+  constexpr int TH = WN * RPW, MBLK = MB * WM, C = 32 * MBLK, NKS = 2 * MBLK;
   constexpr size_t nb_alloc = (size_t)((2 * (TH + 2) * 66 + 63) / 64) * 64;
-  constexpr size_t lds = (size_t)6 * C * 4 + 2 * nb_alloc * 16 + (size_t)2 * MB * 5 * 64 * 16 + (size_t)MB * NKS * 64 * 16 + (size_t)(C / 8) * TH * 64 * 16;
+  constexpr size_t lds = (size_t)6 * C * 4 + 2 * nb_alloc * 16 + (size_t)2 * MBLK * 5 * 64 * 16 + (W3RES ? (size_t)MBLK * NKS * 64 * 16 : 0) +
+                         (size_t)(C / 8) * TH * 64 * 16;
   static_assert(lds <= 160 * 1024, "tile does not fit in LDS");
   a.tiles_x = (a.W + 63) / 64;
   a.tiles_y = (a.H + TH - 1) / TH;
@@ -289,19 +302,19 @@ int launch_tail(TailArgs& a, hipStream_t st) {
   if (nt <= 0 || nt > 0x7fffffffLL) return SLU_EUNSUPPORTED;
   long long gx = 256;                                                 // one 8-wave workgroup per CU (LDS)
   if (gx > nt) gx = nt;
-  auto kern = tail_h8_kernel<MB, WN, RPW>;
+  auto kern = tail_h8_kernel<MB, WM, WN, RPW, W3RES>;
   static bool attr_set = false;                                       // benign race: the call is idempotent
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SLU_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(64 * WN), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(64 * WM * WN), lds, st, a);
   SLU_CHECK_LAUNCH();
 }
 
 }  // namespace
 
-extern "C" int slu_conv_tail_h8_supported(int C, int H, int W) { return (C == 32 || C == 64) && H > 0 && W > 0 ? 1 : 0; }
+extern "C" int slu_conv_tail_h8_supported(int C, int H, int W) { return (C == 32 || C == 64 || C == 128) && H > 0 && W > 0 ? 1 : 0; }
 
 extern "C" int slu_conv_tail_h8_fwd(const slu_conv_tail_h8_desc* d, slu_stream_t stream) {
   if (!d || !d->a1 || !d->a2 || !d->w2x2 || !d->w1x1 || !d->out || d->N <= 0 || d->H <= 0 || d->W <= 0) return SLU_EINVAL;
@@ -323,5 +336,7 @@ extern "C" int slu_conv_tail_h8_fwd(const slu_conv_tail_h8_desc* d, slu_stream_t
   a.out = reinterpret_cast<uint2*>(d->out);
   a.N = d->N; a.H = d->H; a.W = d->W; a.G = d->C / 8;
   hipStream_t st = slu_stream(stream);
-  return d->C == 32 ? launch_tail<1, 8, 2>(a, st) : launch_tail<2, 8, 1>(a, st);
+  if (d->C == 32) return launch_tail<1, 1, 8, 2, true>(a, st);
+  if (d->C == 64) return launch_tail<2, 1, 8, 1, true>(a, st);
+  return launch_tail<2, 2, 4, 1, false>(a, st);
 }

@@ -202,7 +202,8 @@ def conv_tail_h8(a1: torch.Tensor, a2: torch.Tensor, w2x2: torch.Tensor, w1x1: t
     # the layer-granular convention of SURVEY 8(d): both convs read their inputs and write their outputs once
     flops = 2.0 * c * c * (4 + 3) * n * h * w
     nbytes = n * h * w * 2.0 * (c + c + 3 * c + c) + 2.0 * c * c * (4 + 3)
-    ops.TIMING.append((f"tail_h8_kernel<{c // 32}, 8, {2 if c == 32 else 1}>", flops, nbytes, e0, e1))
+    name = {32: "tail_h8_kernel<1, 1, 8, 2, true>", 64: "tail_h8_kernel<2, 1, 8, 1, true>", 128: "tail_h8_kernel<2, 2, 4, 1, false>"}[c]
+    ops.TIMING.append((name, flops, nbytes, e0, e1))
     ops.TIMING_TAGS.append(f"N{n} {c}->{c} k2d2 + {3 * c}->{c} k1 fused {h}x{w}")
     return out
 

@@ -40,6 +40,8 @@ _CONV_PRECISION = os.environ.get("SLU_CONV_PRECISION", "fp32")
 _TRAIN_CONV_PRECISION = os.environ.get("SLU_TRAIN_CONV_PRECISION", "fp32")
 # half-precision inference: run a block's 2x2-dilated conv and its concat 1x1 conv as one launch (0: two launches; A/B switch)
 _FUSE_TAIL = os.environ.get("SLU_FUSE_TAIL", "1") != "0"
+# the fused kernel also covers 128 channels, but there (MFMA-bound layers, 4-row tiles) it measured slower than the two launches
+_FUSE_TAIL_MAX_C = int(os.environ.get("SLU_FUSE_TAIL_MAX_C", "64"))
 
 
 def set_train_conv_precision(precision: str) -> None:
@@ -117,7 +119,7 @@ class _FusedBlock(nn.Module):
         c = conv_a.out_channels
         if (_FUSE_TAIL and a1.dtype == torch.float16 and a1.dim() == 5 and conv_a.kernel_size == (2, 2) and conv_a.dilation == (2, 2)
                 and conv_b.kernel_size == (1, 1) and conv_b.in_channels == 3 * c and conv_b.out_channels == c
-                and h8.conv_tail_supported(c, a1.shape[2], a1.shape[3])):
+                and c <= _FUSE_TAIL_MAX_C and h8.conv_tail_supported(c, a1.shape[2], a1.shape[3])):
             packs, folded = [], []
             for conv, bn in ((conv_a, bn_a), (conv_b, bn_b)):
                 p = self._prepared(conv)

@@ -42,7 +42,7 @@ def _case(cuda, c, n, hh, ww, resid, seed, slope_a=0.01, slope_b=0.01, bn=True):
     assert float((fused - ref).abs().max()) <= 1e-2 * scale, (c, n, hh, ww, float((fused - ref).abs().max()), scale)
 
 
-@pytest.mark.parametrize("c", [32, 64])
+@pytest.mark.parametrize("c", [32, 64, 128])
 def test_tail_matches_unfused_and_fp32(cuda, c):
     _case(cuda, c, 2, 64, 256, True, 1)
     _case(cuda, c, 3, 16, 64, False, 2)                                    # one tile column, several images
@@ -54,7 +54,8 @@ def test_tail_matches_unfused_and_fp32(cuda, c):
 def test_tail_many_tiles_and_argument_checks(cuda):
     _case(cuda, 64, 6, 64, 2048, True, 6)                                  # 6 x 8 x 32 = 1536 tiles: six rounds of the persistent grid
     _case(cuda, 32, 5, 64, 2048, False, 7)
-    assert h8.conv_tail_supported(32, 64, 2048) and h8.conv_tail_supported(64, 32, 1024) and not h8.conv_tail_supported(128, 32, 1024)
-    x = h8.to_h8(torch.zeros(1, 128, 8, 64, device=cuda))
+    _case(cuda, 128, 9, 32, 1024, True, 8)                                  # 9 x 8 x 16 = 1152 tiles of 4 rows
+    assert h8.conv_tail_supported(32, 64, 2048) and h8.conv_tail_supported(64, 32, 1024) and h8.conv_tail_supported(128, 32, 1024) and not h8.conv_tail_supported(256, 16, 512)
+    x = h8.to_h8(torch.zeros(1, 256, 8, 64, device=cuda))
     with pytest.raises(RuntimeError):
         h8.conv_tail_h8(x, x, torch.zeros(1, dtype=torch.uint8, device=cuda), torch.zeros(1, dtype=torch.uint8, device=cuda), None, None, None, None, None, None)
