@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--graph", action="store_true",
-                    help="capture fwd + loss + bwd + AdamW into one HIP graph and replay it (single GPU; removes the ~1000 launch gaps)")
+                    help="replay fwd + loss + bwd (+ AdamW on one GPU) as one HIP graph (semanticlidarunc_amd.graph_step; removes the ~1000 launch gaps)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
                     help="products of the forward convs (storage and accumulation stay fp32; dgrad / wgrad are always exact fp32)")
     a = ap.parse_args()
@@ -43,7 +43,8 @@ def main():
     broadcast_parameters(model)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, capturable=a.graph)
     red = FlatGradAllReduce(model.parameters())
-    red.attach_to_optimizer(opt)
+    if not a.graph:
+        red.attach_to_optimizer(opt)
     x, y = synthetic_scan(a.batch, a.height, a.width, seed=1234 + rank)
     x, y = x.to(dev), y.to(dev)
     torch.manual_seed(7 + rank)
@@ -64,18 +65,10 @@ def main():
         step()
     sync()
     if a.graph:
-        if world > 1:
-            raise SystemExit("--graph is a single-GPU option (the gradient all-reduce hook is not captured)")
-        graph = torch.cuda.HIPGraph() if hasattr(torch.cuda, "HIPGraph") else torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step()                                   # warm-up on the capture stream (lazy attribute / allocator state)
-        torch.cuda.current_stream().wait_stream(side)
-        opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
-            static_loss = step()
-        run = lambda: (graph.replay(), static_loss)[1]
+        from semanticlidarunc_amd.graph_step import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt, lambda out, t: salsanext_loss(out, t, 1.0, 1.0, 0)[0], x, y,
+                                   reducer=red if world > 1 else None)      # multi-GPU: the all-reduce + update follow the replay
+        run = lambda: graphed(x, y)
     else:
         run = step
     sync()
