@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 13
+#define SLU_ABI_VERSION 14
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -308,6 +308,13 @@ typedef struct slu_conv_tail_h8_desc {   /* HOST struct */
 } slu_conv_tail_h8_desc;
 int slu_conv_tail_h8_supported(int C, int H, int W);
 int slu_conv_tail_h8_fwd(const slu_conv_tail_h8_desc* desc, slu_stream_t stream);
+
+/* Segmentation head + MC-dropout reduction in one pass on the h8 path (SalsaNext.py:213 + trainer.py:1143-1154):
+ * x: h8 [T*B][G][HW][8], pass-major (image t*B + b = pass t of scan b), 8 G = input channels of the head (G in {2, 4, 8});
+ * wpack = slu_pack_conv_weight_h8 of the head's [C][8 G][1][1] weight (C <= 32); bias [C] or NULL.  Outputs as slu_mc_reduce:
+ * p_bar fp32 [B][C][HW], h_norm / mi_norm fp32 [B][HW], preds int64 [B][HW].  HW % 32 == 0. */
+int slu_head_mc_h8(const void* x, int T, int B, int G, int HW, const void* wpack, const float* bias, int C, float eps, float* p_bar,
+                   float* h_norm, float* mi_norm, int64_t* preds, slu_stream_t stream);
 
 /* ---- Dirichlet head (the reference's default loss path, configs/SemanticKitti_default.yaml:10) ---------------
  * alpha = 1 + softplus(scale / T) * softmax(shape) + eps   (probability_helper.py:89-105; trainer.py:533-535 splits the C+1

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -152,6 +152,8 @@ SIGNATURES = {
                                          c_stream]),
     "slu_conv_tail_h8_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "slu_conv_tail_h8_fwd": (C.c_int, [C.POINTER(ConvTailH8Desc), c_stream]),
+    "slu_head_mc_h8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_f32p, C.c_int, C.c_float, c_f32p, c_f32p, c_f32p,
+                                 c_i64p, c_stream]),
     "slu_build_normals": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_stream]),
     "slu_group_by_class_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "slu_group_by_class": (C.c_int, [c_i64p, c_f32p, C.c_longlong, C.c_int, c_f32p, c_i64p, C.c_void_p, C.c_size_t, c_stream]),

@@ -208,6 +208,43 @@ def conv_tail_h8(a1: torch.Tensor, a2: torch.Tensor, w2x2: torch.Tensor, w1x1: t
     return out
 
 
+def head_mc_h8(x: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor], classes: int, passes: int, batch: int, eps: float = 1e-12):
+    """x: h8 [T*B, G, H, W, 8] (pass-major) -> (p_bar [B,C,H,W], H_norm [B,H,W], MI_norm [B,H,W], preds int64 [B,H,W]): the 1x1 head
+    conv and the MC-dropout reduction of trainer.py:1143-1154 in one launch (slu_head_mc_h8)."""
+    _req_h8(x, "x")
+    n, g, h, w, _ = x.shape
+    if n != passes * batch:
+        raise RuntimeError(f"head_mc_h8: {n} images != T * B = {passes} * {batch}")
+    lib = _lib.load()
+    _req(wpack, "wpack", torch.uint8)
+    if wpack.numel() != lib.slu_packed_weight_bytes_h8(classes, 8 * g, 1):
+        raise RuntimeError("head_mc_h8: packed weight size does not match the head")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != classes:
+            raise RuntimeError(f"bias: expected {classes} elements, got {bias.numel()}")
+    dev = x.device
+    p_bar = torch.empty((batch, classes, h, w), dtype=torch.float32, device=dev)
+    hn = torch.empty((batch, h, w), dtype=torch.float32, device=dev)
+    mi = torch.empty((batch, h, w), dtype=torch.float32, device=dev)
+    preds = torch.empty((batch, h, w), dtype=torch.int64, device=dev)
+    args = (x.data_ptr(), passes, batch, g, h * w, wpack.data_ptr(), _ptr(bias), classes, float(eps), p_bar.data_ptr(), hn.data_ptr(),
+            mi.data_ptr(), preds.data_ptr(), _stream())
+    if ops.TIMING is None:
+        check(lib.slu_head_mc_h8(*args), "slu_head_mc_h8")
+        return p_bar, hn, mi, preds
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.slu_head_mc_h8(*args), "slu_head_mc_h8")
+    e1.record()
+    # layer-granular accounting: the head conv reads its fp16 input and "writes" fp32 logits; the epilogue of SURVEY 8(d) reads them back
+    flops = 2.0 * 8 * g * classes * n * h * w
+    nbytes = n * h * w * (2.0 * 8 * g + 4.0 * classes) + 2.0 * classes * 8 * g
+    ops.TIMING.append((f"head_mc_h8_kernel<{g // 2}>", flops, nbytes, e0, e1))
+    ops.TIMING_TAGS.append(f"N{n} {8 * g}->{classes} k1 head + MC reduce T={passes} {h}x{w}")
+    return p_bar, hn, mi, preds
+
+
 def avgpool3s2_h8(x: torch.Tensor, scale: Optional[torch.Tensor] = None, n_out: Optional[int] = None) -> torch.Tensor:
     """AvgPool2d(3, 2, 1) of x[n % B] * scale[n] for n < n_out (n_out = B unless x is shared by stacked MC passes)."""
     _req_h8(x, "x")

@@ -42,6 +42,8 @@ _TRAIN_CONV_PRECISION = os.environ.get("SLU_TRAIN_CONV_PRECISION", "fp32")
 _FUSE_TAIL = os.environ.get("SLU_FUSE_TAIL", "1") != "0"
 # the fused kernel also covers 128 channels, but there (MFMA-bound layers, 4-row tiles) it measured slower than the two launches
 _FUSE_TAIL_MAX_C = int(os.environ.get("SLU_FUSE_TAIL_MAX_C", "64"))
+# half-precision MC inference: head conv + softmax / entropy / MI reduction over the T passes as one launch (0: logits + slu_mc_reduce)
+_FUSE_HEAD_MC = os.environ.get("SLU_FUSE_HEAD_MC", "1") != "0"
 
 
 def set_train_conv_precision(precision: str) -> None:
@@ -326,6 +328,35 @@ class SalsaNext(_FusedBlock):
         return self._forward(x, scales)
 
     @torch.no_grad()
+    def _head(self, u1):
+        """The 1x1 logits conv; with `_features_only` set (mc_predict_fused) the decoder output is handed back instead."""
+        if self.__dict__.get("_features_only", False):
+            return u1
+        return self._run(self.logits, None, [ConvSource(u1)], act=False, out_f32=True)
+
+    def mc_fused_ok(self, x, T: int) -> bool:
+        """The fused head + MC reduction covers half-precision inference on images whose pixel count is a multiple of 32."""
+        return (_FUSE_HEAD_MC and _CONV_PRECISION == "f16" and isinstance(x, torch.Tensor) and x.dim() == 4 and x.is_cuda
+                and (x.shape[2] * x.shape[3]) % 32 == 0 and self.logits.out_channels <= 32 and self._inference_only())
+
+    @torch.no_grad()
+    def mc_predict_fused(self, x, T: int, eps: float = 1e-12, share_prefix: bool = False, scales=None):
+        """(p_bar, H_norm, MI_norm, preds) of T stochastic passes with the head conv and the MC reduction in one launch
+        (csrc/head_mc_h8.hip): the T*B fp32 logit maps are never written.  Call under utils.mc_dropout.dropout_sampling."""
+        b = x.shape[0]
+        self.__dict__["_features_only"] = True
+        try:
+            u1 = self.forward_mc(x, T, scales) if share_prefix else self._forward(x.repeat(int(T), 1, 1, 1), scales)
+        finally:
+            self.__dict__["_features_only"] = False
+        p = self._prepared(self.logits)
+        wkey = _tkey(self.logits.weight)
+        if p.key8 != wkey:
+            p.wpack8 = h8.pack_conv_weight_h8(self.logits.weight.detach().contiguous())
+            p.key8 = wkey
+        return h8.head_mc_h8(u1, p.wpack8, None if self.logits.bias is None else self.logits.bias.detach(), self.logits.out_channels,
+                             int(T), b, eps)
+
     def forward_mc(self, x, T: int, scales: Optional[Dict[str, torch.Tensor]] = None):
         """T stochastic passes of a batch x[B,...] -> logits [T*B, ncls, H, W] (pass-major), computing the part of
         the network that no active Dropout2d can reach ONCE: the three context blocks, resBlock1 and the convs of
@@ -358,7 +389,7 @@ class SalsaNext(_FusedBlock):
         u3, s = self.upBlock2(u4, d2b, s, scales, "upBlock2")
         u2, s = self.upBlock3(u3, full2, s, scales, "upBlock3", skip_nbatch=b)
         u1, _ = self.upBlock4(u2, d0b, s, scales, "upBlock4", skip_nbatch=b)
-        return self._run(self.logits, None, [ConvSource(u1)], act=False, out_f32=True)
+        return self._head(u1)
 
     def _inference_only(self) -> bool:
         """True when no autograd graph is wanted and every BatchNorm is frozen (the half-precision path has no backward)."""
@@ -389,4 +420,4 @@ class SalsaNext(_FusedBlock):
         u3, s = self.upBlock2(u4, d2b, s, scales, "upBlock2")
         u2, s = self.upBlock3(u3, d1b, s, scales, "upBlock3")
         u1, _ = self.upBlock4(u2, d0b, s, scales, "upBlock4")
-        return self._run(self.logits, None, [ConvSource(u1)], act=False, out_f32=True)
+        return self._head(u1)

@@ -106,6 +106,12 @@ def predictive_entropy_mc(mc_probs: torch.Tensor, eps: float = 1e-12, normalize:
 def mc_predict(model: nn.Module, inputs, T: int = 30, eps: float = 1e-12, share_prefix: bool = False):
     """The whole MC evaluation step of trainer.py:1138-1154 in one call:
     (p_bar[B,C,H,W], H_norm[B,H,W], MI_norm[B,H,W], preds[B,H,W])."""
+    xs = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+    if len(xs) == 1 and T <= MAX_STACK and hasattr(model, "mc_predict_fused"):
+        model.eval()
+        if model.mc_fused_ok(xs[0], T):                 # half-precision SalsaNext: head conv + reduction in one launch, no logit maps
+            with dropout_sampling(model, enable=True):
+                return model.mc_predict_fused(xs[0], T, eps, share_prefix)
     return ops.mc_reduce(mc_forward(model, inputs, T, share_prefix).contiguous(), eps)
 
 
