@@ -327,7 +327,6 @@ class SalsaNext(_FusedBlock):
         (site name -> [B,C,1,1] or [B,C]; missing site = identity).  Used by the parity tests."""
         return self._forward(x, scales)
 
-    @torch.no_grad()
     def _head(self, u1):
         """The 1x1 logits conv; with `_features_only` set (mc_predict_fused) the decoder output is handed back instead."""
         if self.__dict__.get("_features_only", False):
@@ -357,6 +356,7 @@ class SalsaNext(_FusedBlock):
         return h8.head_mc_h8(u1, p.wpack8, None if self.logits.bias is None else self.logits.bias.detach(), self.logits.out_channels,
                              int(T), b, eps)
 
+    @torch.no_grad()
     def forward_mc(self, x, T: int, scales: Optional[Dict[str, torch.Tensor]] = None):
         """T stochastic passes of a batch x[B,...] -> logits [T*B, ncls, H, W] (pass-major), computing the part of
         the network that no active Dropout2d can reach ONCE: the three context blocks, resBlock1 and the convs of
