@@ -249,5 +249,10 @@ def test_ouster_shape_128x4096_T16(cuda):
         assert bool(torch.isfinite(p_bar).all()) and float((p_bar.sum(1) - 1).abs().max()) <= 1e-5
         assert float(h_norm.min()) >= 0 and float(h_norm.max()) <= 1 + 1e-6 and float(mi_norm.min()) >= 0
         assert float((mi_norm - h_norm).max()) <= 1e-6             # MI <= H
+        # the fused head + MC reduction at this size, same multipliers, both schedules: same maps as reducing the stored logits
+        for share in (False, True):
+            fp, fh, fm, fa = model.mc_predict_fused(x.to(cuda), t, share_prefix=share, scales=oscales)
+            assert float((fp - p_bar).abs().max()) <= 2e-6 and float((fh - h_norm).abs().max()) <= 2e-5
+            assert float((fm - mi_norm).abs().max()) <= 2e-5 and int((fa != preds).sum()) <= 4
     finally:
         sn.set_conv_precision("fp32")
