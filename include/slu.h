@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 14
+#define SLU_ABI_VERSION 15
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -353,6 +353,16 @@ int slu_ua_samples(const int64_t* labels, const int64_t* preds, const float* unc
                    float* u_out, uint8_t* flags, slu_stream_t stream);
 int slu_binned_counts(const float* u, const uint8_t* correct, long long n, const float* edges, int n_bins, int64_t* count, int64_t* n_correct,
                       slu_stream_t stream);
+
+/* ---- ECE sample buffers (metrics/ece.py:55-111,115-140 ECEAggregator with max_samples / binning='adaptive') ----------
+ * slu_ece_samples: per pixel conf = clamp(max_c p_c, 0, 1) with p by mode (0 alpha: a / (sum a + eps); 1 logits: softmax; 2 probs:
+ *   clamp >= 0, / max(sum, eps); ece.py:55-64) and flags = 1 argmax == label / 0 otherwise / 2 label == ignore_index (has_ignore)
+ *   (:75-84).  preds [B,C,HW], C <= 32; conf f32 [B,HW], flags u8 [B,HW].
+ * slu_binned_stats: slu_binned_counts plus sum_u[b] += sum of u over bin b (f64): the three np.histogram calls of :136-140. */
+int slu_ece_samples(const float* preds, const int64_t* labels, int B, int C, int HW, int mode, int has_ignore, int64_t ignore_index, float eps,
+                    float* conf, uint8_t* flags, slu_stream_t stream);
+int slu_binned_stats(const float* u, const uint8_t* correct, long long n, const float* edges, int n_bins, int64_t* count, int64_t* n_correct,
+                     double* sum_u, slu_stream_t stream);
 
 /* ---- per-class sample lists (models/evaluator.py:211-232 UncertaintyPerClassAggregator.update) --------------------
  * out_values = [values[labels == 0] ..., values[labels == 1] ..., ...] in scan order inside each class (what the reference's boolean

@@ -41,25 +41,24 @@ def iou_from_confusion(cm, test_mask=None, ignore_gt=None):
 
 
 def top_label(probs, labels, ignore_index=None, mode="probs", eps=1e-12):
-    """(conf float32[n], correct bool[n]) over valid pixels in NCHW scan order (ece.py:55-84)."""
-    p = np.asarray(probs, dtype=np.float32)
+    """(conf float32[n], correct bool[n]) over valid pixels in NCHW scan order (ece.py:55-84), in torch CPU fp32 ops so that the
+    class sums round exactly as the reference's do."""
+    import torch
+    x = torch.as_tensor(np.asarray(probs, dtype=np.float32))
     if mode == "probs":
-        p = np.maximum(p, 0)
-        p = p / np.maximum(p.sum(axis=1, keepdims=True), np.float32(eps))
+        p = x.clamp_min(0)
+        p = p / p.sum(dim=1, keepdim=True).clamp_min(eps)
     elif mode == "alpha":
-        p = p / (p.sum(axis=1, keepdims=True) + np.float32(eps))
+        p = x / (x.sum(dim=1, keepdim=True) + eps)
     elif mode == "logits":
-        z = p - p.max(axis=1, keepdims=True)
-        e = np.exp(z)
-        p = e / e.sum(axis=1, keepdims=True)
+        p = x.softmax(dim=1)
     else:
         raise ValueError(mode)
-    conf = p.max(axis=1)
-    pred = p.argmax(axis=1)
-    lab = np.asarray(labels).astype(np.int64)
-    valid = np.ones_like(lab, bool) if ignore_index is None else lab != ignore_index
-    conf = np.clip(conf[valid].astype(np.float32), 0.0, 1.0)
-    return conf, pred[valid] == lab[valid]
+    conf, pred = p.max(dim=1)
+    lab = torch.as_tensor(np.asarray(labels)).long()
+    valid = torch.ones_like(lab, dtype=torch.bool) if ignore_index is None else lab != ignore_index
+    conf = conf[valid].to(torch.float32).view(-1).clamp_(0, 1)
+    return conf.numpy(), (pred[valid].view(-1) == lab[valid].view(-1)).numpy()
 
 
 def ece_bins(conf, correct, n_bins: int = 15):
@@ -83,6 +82,62 @@ def ece_from_bins(n, acc_s, conf_s):
     conf = np.divide(conf_s, n, out=np.zeros_like(n), where=n > 0)
     gap = np.abs(acc - conf)
     return float(np.sum(n / max(1.0, n.sum()) * gap)), float(np.max(gap[n > 0]))
+
+
+class ECESamples:
+    """ece.py:86-111 (ECEAggregator.update after the top-label step): the (confidence, correct) sample buffers with the optional
+    reservoir cap -- fill up to `max_samples` (a uniformly drawn subset of a batch that does not fit), afterwards keep each new sample
+    with probability max_samples / seen and overwrite uniformly drawn slots.  One numpy Generator(seed), draws in the reference's order."""
+
+    def __init__(self, max_samples=None, seed=0):
+        self.max_samples, self.rng = max_samples, np.random.default_rng(seed)
+        self.conf, self.correct, self.seen = np.empty(0, np.float32), np.empty(0, bool), 0
+
+    def update(self, conf, correct):
+        conf, correct = np.asarray(conf, np.float32), np.asarray(correct, bool)
+        n_new = conf.size
+        if n_new == 0:                       # ece.py:80-81: a batch without valid pixels changes nothing
+            return
+        self.seen += n_new
+        if self.max_samples is None:
+            self.conf, self.correct = np.concatenate([self.conf, conf]), np.concatenate([self.correct, correct])
+        elif self.conf.size < self.max_samples:
+            take = min(self.max_samples - self.conf.size, n_new)
+            if take < n_new:
+                idx = self.rng.choice(n_new, size=take, replace=False)
+                conf, correct = conf[idx], correct[idx]
+            self.conf, self.correct = np.concatenate([self.conf, conf]), np.concatenate([self.correct, correct])
+        else:
+            keep = self.rng.random(n_new) < min(1.0, float(self.max_samples) / float(self.seen + 1e-9))
+            if keep.any():
+                conf, correct = conf[keep], correct[keep]
+                slots = self.rng.choice(self.max_samples, size=conf.size, replace=False)
+                self.conf[slots], self.correct[slots] = conf, correct
+
+
+def ece_edges(conf, n_bins: int = 15, binning: str = "uniform"):
+    """ece.py:114-128 (_bin_edges): float32 linspace; 'adaptive' = empirical quantiles of the stored confidences, ends pinned to
+    0 / 1, duplicates removed, falling back to the uniform edges when fewer than n_bins + 1 distinct edges remain."""
+    uniform = np.linspace(0.0, 1.0, n_bins + 1, dtype=np.float32)
+    conf = np.asarray(conf, np.float32)
+    edges = uniform
+    if binning == "adaptive" and conf.size:
+        edges = np.quantile(conf, np.linspace(0.0, 1.0, n_bins + 1, dtype=np.float32))
+        edges[0], edges[-1] = 0.0, 1.0
+        edges = np.unique(edges)
+        if edges.size < n_bins + 1:
+            edges = uniform
+    edges[0], edges[-1] = 0.0, 1.0
+    return edges
+
+
+def ece_bins_over(conf, correct, edges):
+    """(n int64, sum_correct f64, sum_conf f64) over explicit edges: the three np.histogram calls of ece.py:136-140."""
+    conf = np.asarray(conf, np.float32)
+    n = np.histogram(conf, bins=edges)[0].astype(np.int64)
+    acc_s = np.histogram(conf, bins=edges, weights=np.asarray(correct, np.float32))[0]
+    conf_s = np.histogram(conf, bins=edges, weights=conf)[0]
+    return n, acc_s.astype(np.float64), conf_s.astype(np.float64)
 
 
 # ---- AUROC of error detection (src/metrics/auroc.py:36-78), restated with torch CPU ops / numpy ------------------------------

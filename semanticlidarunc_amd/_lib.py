@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -142,6 +142,8 @@ SIGNATURES = {
     "slu_auroc_compute": (C.c_int, [c_f32p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_size_t, c_f64p, c_f32p, C.c_void_p, c_stream]),
     "slu_ua_samples": (C.c_int, [c_i64p, c_i64p, c_f32p, C.c_longlong, c_i64p, C.c_int, c_f32p, C.c_void_p, c_stream]),
     "slu_binned_counts": (C.c_int, [c_f32p, C.c_void_p, C.c_longlong, c_f32p, C.c_int, c_i64p, c_i64p, c_stream]),
+    "slu_ece_samples": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, c_f32p, C.c_void_p, c_stream]),
+    "slu_binned_stats": (C.c_int, [c_f32p, C.c_void_p, C.c_longlong, c_f32p, C.c_int, c_i64p, c_i64p, c_f64p, c_stream]),
     "slu_tversky_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int,
                                   c_f64p, c_f32p, c_f32p, c_f32p, c_stream]),
     "slu_tversky_bwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float, c_f32p, c_f32p,

@@ -455,12 +455,8 @@ int launch_1x1(ConvArgs& a, hipStream_t st) {
   const long long gx = (nblocks + 4 * NBW - 1) / (4 * NBW);
   if (gx <= 0 || gx > 0x7fffffffLL) return SLU_EUNSUPPORTED;
   auto kern = conv1x1_f16x3_kernel<MB, NBW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SLU_ELAUNCH;
-    attr_set = true;
-  }
+  static SluLdsGrant grant;
+  if (slu_grant_dynamic_lds(reinterpret_cast<const void*>(kern), lds, grant) != SLU_OK) return SLU_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, a, a.resid, a.out);
   SLU_CHECK_LAUNCH();
 }
@@ -519,12 +515,8 @@ int launch_cfg16(ConvArgs& a, hipStream_t st) {
   const int gy = (a.nmblk + MBLK - 1) / MBLK;
   if (gx <= 0 || gx > 0x7fffffffLL || gy > 65535) return SLU_EUNSUPPORTED;
   auto kern = conv_f16x3_kernel<KS, DIL, PAD, MB, WM, WN, RPW, GEN>;
-  static bool attr_set = false;     // benign race: the call is idempotent
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SLU_ELAUNCH;
-    attr_set = true;
-  }
+  static SluLdsGrant grant;
+  if (slu_grant_dynamic_lds(reinterpret_cast<const void*>(kern), lds, grant) != SLU_OK) return SLU_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64 * WM * WN), lds, st, a, a.resid, a.out);
   SLU_CHECK_LAUNCH();
 }

@@ -906,12 +906,8 @@ int launch_h8_k(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
   if (gx < 8) gx = 8;
   if (gx > nt) gx = nt;
   auto kern = conv_h8_kernel<KS, DIL, PAD, MB, WM, WN, RPW, SCALED, WRES, F32OUT>;
-  static size_t attr_lds = 0;       // benign race: the call is idempotent
-  if (lds > attr_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SLU_ELAUNCH;
-    attr_lds = lds;
-  }
+  static SluLdsGrant grant;
+  if (slu_grant_dynamic_lds(reinterpret_cast<const void*>(kern), lds, grant) != SLU_OK) return SLU_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64 * NWAVE), lds, st, a, d->resid, d->out);
   SLU_CHECK_LAUNCH();
 }

@@ -303,11 +303,8 @@ int launch_tail(TailArgs& a, hipStream_t st) {
   long long gx = 256;                                                 // one 8-wave workgroup per CU (LDS)
   if (gx > nt) gx = nt;
   auto kern = tail_h8_kernel<MB, WM, WN, RPW, W3RES>;
-  static bool attr_set = false;                                       // benign race: the call is idempotent
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SLU_ELAUNCH;
-    attr_set = true;
-  }
+  static SluLdsGrant grant;
+  if (slu_grant_dynamic_lds(reinterpret_cast<const void*>(kern), lds, grant) != SLU_OK) return SLU_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(64 * WM * WN), lds, st, a);
   SLU_CHECK_LAUNCH();
 }

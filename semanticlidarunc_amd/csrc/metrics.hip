@@ -162,6 +162,80 @@ __global__ __launch_bounds__(256) void binned_counts_kernel(const float* __restr
   }
 }
 
+// metrics/ece.py:55-84 (ECEAggregator._to_probs + update): per pixel the top-label confidence of p (by mode: 0 alpha a / (sum a + eps),
+// 1 logits softmax, 2 probs clamp >= 0 then / max(sum, eps)), clamped to [0, 1], and flag = 1 prediction == label / 0 otherwise /
+// 2 label == ignore_index.  Feeds the capped sample buffers of the reservoir mode (:93-111).
+template <int CMAX>
+__global__ __launch_bounds__(256) void ece_samples_kernel(const float* __restrict__ preds, const int64_t* __restrict__ labels, int B, int C, int HW,
+                                                          int mode, int has_ignore, int64_t ignore_index, float eps, float* __restrict__ conf_out,
+                                                          uint8_t* __restrict__ flag_out) {
+  const size_t npix = (size_t)B * HW;
+  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(pix / HW);
+    const int hw = (int)(pix - (size_t)b * HW);
+    const float* src = preds + (size_t)b * C * (size_t)HW + hw;
+    float x[CMAX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      x[c] = (c < C) ? src[(size_t)c * HW] : -INFINITY;
+      if (mode == 2 && c < C) x[c] = fmaxf(x[c], 0.0f);
+      m = fmaxf(m, x[c]);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+        if (mode == 1) x[c] = expf(x[c] - m);
+        s += x[c];
+      }
+    const float den = mode == 0 ? s + eps : (mode == 1 ? s : fmaxf(s, eps));
+    float best = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+        const float p = x[c] / den;
+        if (p > best) { best = p; arg = c; }
+      }
+    const int64_t lab = labels[pix];
+    conf_out[pix] = fminf(fmaxf(best, 0.0f), 1.0f);
+    flag_out[pix] = (has_ignore && lab == ignore_index) ? (uint8_t)2 : (uint8_t)((int64_t)arg == lab ? 1 : 0);
+  }
+}
+
+// np.histogram(u, bins=edges) with weights None / correct / u (metrics/ece.py:136-140): binned_counts_kernel plus the per-bin sum of u.
+__global__ __launch_bounds__(256) void binned_stats_kernel(const float* __restrict__ u, const uint8_t* __restrict__ correct, size_t n,
+                                                           const float* __restrict__ edges, int K, unsigned long long* __restrict__ count,
+                                                           unsigned long long* __restrict__ n_correct, double* __restrict__ sum_u) {
+  __shared__ unsigned s_n[256], s_ok[256];
+  __shared__ float s_u[256];
+  __shared__ float s_edge[257];
+  s_n[threadIdx.x] = 0;
+  s_ok[threadIdx.x] = 0;
+  s_u[threadIdx.x] = 0.0f;
+  for (int i = threadIdx.x; i <= K; i += blockDim.x) s_edge[i] = edges[i];
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = u[i];
+    if (!(v >= s_edge[0] && v <= s_edge[K])) continue;
+    int lo = 0, hi = K;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (v >= s_edge[mid]) lo = mid; else hi = mid;
+    }
+    atomicAdd(&s_n[lo], 1u);
+    if (correct[i]) atomicAdd(&s_ok[lo], 1u);
+    atomicAdd(&s_u[lo], v);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < K && s_n[threadIdx.x]) {
+    atomicAdd(&count[threadIdx.x], (unsigned long long)s_n[threadIdx.x]);
+    atomicAdd(&n_correct[threadIdx.x], (unsigned long long)s_ok[threadIdx.x]);
+    atomicAdd(&sum_u[threadIdx.x], (double)s_u[threadIdx.x]);
+  }
+}
+
 }  // namespace
 
 extern "C" int slu_confusion_update(const int64_t* preds, const int64_t* targets, int64_t n, int C, int64_t* confmat,
@@ -220,6 +294,29 @@ extern "C" int slu_binned_counts(const float* u, const uint8_t* correct, long lo
   SLU_CHECK_LAUNCH();
 }
 
+
+extern "C" int slu_ece_samples(const float* preds, const int64_t* labels, int B, int C, int HW, int mode, int has_ignore, int64_t ignore_index,
+                               float eps, float* conf, uint8_t* flags, slu_stream_t stream) {
+  if (!preds || !labels || !conf || !flags || B <= 0 || C <= 0 || HW <= 0 || mode < 0 || mode > 2) return SLU_EINVAL;
+  if (C > 32) return SLU_EUNSUPPORTED;
+  const unsigned g = grid_for((size_t)B * HW, 4096);
+  if (C <= 20)
+    hipLaunchKernelGGL(ece_samples_kernel<20>, dim3(g), dim3(256), 0, slu_stream(stream), preds, labels, B, C, HW, mode, has_ignore, ignore_index,
+                       eps, conf, flags);
+  else
+    hipLaunchKernelGGL(ece_samples_kernel<32>, dim3(g), dim3(256), 0, slu_stream(stream), preds, labels, B, C, HW, mode, has_ignore, ignore_index,
+                       eps, conf, flags);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_binned_stats(const float* u, const uint8_t* correct, long long n, const float* edges, int n_bins, int64_t* count,
+                                int64_t* n_correct, double* sum_u, slu_stream_t stream) {
+  if (!u || !correct || !edges || !count || !n_correct || !sum_u || n <= 0 || n_bins <= 0) return SLU_EINVAL;
+  if (n_bins > 256) return SLU_EUNSUPPORTED;
+  hipLaunchKernelGGL(binned_stats_kernel, dim3(grid_for((size_t)n, 2048)), dim3(256), 0, slu_stream(stream), u, correct, (size_t)n, edges, n_bins,
+                     reinterpret_cast<unsigned long long*>(count), reinterpret_cast<unsigned long long*>(n_correct), sum_u);
+  SLU_CHECK_LAUNCH();
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Samples grouped by class, stable (models/evaluator.py:211-232 UncertaintyPerClassAggregator.update: the

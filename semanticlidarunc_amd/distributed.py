@@ -24,6 +24,13 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if torch.cuda.is_available() and (backend or "nccl") == "nccl":
+        # one process per GPU: make local_rank's card the current device BEFORE anything allocates -- the reference's Trainer
+        # uses the bare torch.device("cuda") (trainer.py:229), which is the current device, and every launch of this package
+        # goes to the current device's stream
+        torch.cuda.set_device(local_rank)
+        if device is None:
+            device = torch.device("cuda", local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -85,7 +92,7 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        dist.broadcast(t, src=src, group=group)      # on the tensor itself (not .data): the write bumps its version counter
 
 
 @torch.no_grad()
@@ -96,40 +103,66 @@ def average_buffers(module: torch.nn.Module, group=None) -> None:
     world = dist.get_world_size(group)
     for b in module.buffers():
         if b.is_floating_point():
-            dist.all_reduce(b.data, op=dist.ReduceOp.SUM, group=group)
-            b.data.mul_(1.0 / world)
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)     # in place on the buffer itself: version counter bumped, so the
+            b.mul_(1.0 / world)                                      # folded eval-BatchNorm caches (salsanext._tkey) are rebuilt
 
 
 @torch.no_grad()
-def all_reduce_metrics(iou=None, ece=None, group=None) -> None:
+def all_reduce_metrics(iou=None, ece=None, group=None, device: Optional[torch.device] = None) -> None:
     """Sum the on-device metric accumulators over the ranks: the [C,C] int64 confusion matrix of
-    models.evaluator.IoUEvaluator and the per-bin (count, sum_correct, sum_conf) of metrics.ece.ECEAggregator."""
+    models.evaluator.IoUEvaluator and the evidence of metrics.ece.ECEAggregator (per-bin sums, or its sample buffers).
+    EVERY rank enters every collective: a rank that saw no batch contributes zero accumulators allocated on `device`
+    (default: the current GPU, or the CPU without one)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    if iou is not None and iou.confmat is not None:
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    if iou is not None:
+        if iou.confmat is None:
+            if hasattr(iou, "_ensure"):
+                iou._ensure(device)
+            else:
+                raise RuntimeError("all_reduce_metrics: the IoU accumulator is unallocated on this rank (the other ranks would wait forever)")
         dist.all_reduce(iou.confmat, op=dist.ReduceOp.SUM, group=group)
-    if ece is not None and ece._count is not None:
-        for t in (ece._count, ece._sum_correct, ece._sum_conf):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if ece is not None:
+        if hasattr(ece, "merge_across_ranks"):
+            if not getattr(ece, "_keeps_samples", False):
+                ece._ensure(device)
+            ece.merge_across_ranks(group)
+        else:
+            for t in (ece._count, ece._sum_correct, ece._sum_conf):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
 class ShardedSampler(torch.utils.data.Sampler):
-    """Disjoint shards of one seeded permutation (the reference shuffles in a single process,
-    src/train_semantics.py:114); every rank sees len(dataset) // world samples per epoch."""
+    """Disjoint shards of one seeded permutation (the reference shuffles in a single process, src/train_semantics.py:114).
+    drop_last=True (training: equal shard sizes keep the gradient average exact) gives every rank
+    len(dataset) // world samples; drop_last=False (evaluation) hands the n % world left-over samples to the LAST ranks, one each,
+    so every sample is evaluated exactly once and nothing is padded."""
 
-    def __init__(self, n: int, rank: int, world: int, seed: int = 0, shuffle: bool = True):
+    def __init__(self, n: int, rank: int, world: int, seed: int = 0, shuffle: bool = True, drop_last: bool = True):
         self.n, self.rank, self.world, self.seed, self.shuffle, self.epoch = n, rank, world, seed, shuffle, 0
+        self.drop_last = drop_last
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
 
+    def _bounds(self):
+        per, rem = divmod(self.n, self.world)
+        if self.drop_last:
+            return self.rank * per, (self.rank + 1) * per
+        first_big = self.world - rem                       # ranks >= first_big take per + 1
+        lo = self.rank * per + max(0, self.rank - first_big)
+        return lo, lo + per + (1 if self.rank >= first_big else 0)
+
     def __len__(self) -> int:
-        return self.n // self.world
+        lo, hi = self._bounds()
+        return hi - lo
 
     def __iter__(self) -> Iterator[int]:
         if self.shuffle:
             order = torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + self.epoch)).tolist()
         else:
             order = list(range(self.n))
-        per = self.n // self.world
-        return iter(order[self.rank * per:(self.rank + 1) * per])
+        lo, hi = self._bounds()
+        return iter(order[lo:hi])

@@ -144,7 +144,7 @@ def conv2d_h8(srcs: Sequence[H8Source], wpack: torch.Tensor, cin: int, cout: int
     e1.record()
     flops = 2.0 * cin * cout * ksize * ksize * n * h * w
     nbytes = n * h * w * (2.0 * cin + (4.0 if out_f32_nchw else 2.0) * cout) + 2.0 * cout * cin * ksize * ksize
-    ops.TIMING.append((buf.value.decode(), flops, nbytes, e0, e1))
+    ops.TIMING.append((buf.value.decode(), flops, nbytes, e0, e1, nbytes + (n * h * w * 2.0 * cout if resid is not None else 0.0)))
     ops.TIMING_TAGS.append(f"N{n} {cin}->{cout} k{ksize}d{dil} {h}x{w}")
     return out
 
@@ -202,8 +202,10 @@ def conv_tail_h8(a1: torch.Tensor, a2: torch.Tensor, w2x2: torch.Tensor, w1x1: t
     # the layer-granular convention of SURVEY 8(d): both convs read their inputs and write their outputs once
     flops = 2.0 * c * c * (4 + 3) * n * h * w
     nbytes = n * h * w * 2.0 * (c + c + 3 * c + c) + 2.0 * c * c * (4 + 3)
+    # what the fused kernel must move: a1, a2 (+ shortcut) in, out once, weights
+    min_bytes = n * h * w * 2.0 * c * (3 + (1 if resid is not None else 0)) + 2.0 * c * c * (4 + 3)
     name = {32: "tail_h8_kernel<1, 1, 8, 2, true>", 64: "tail_h8_kernel<2, 1, 8, 1, true>", 128: "tail_h8_kernel<2, 2, 4, 1, false>"}[c]
-    ops.TIMING.append((name, flops, nbytes, e0, e1))
+    ops.TIMING.append((name, flops, nbytes, e0, e1, min_bytes))
     ops.TIMING_TAGS.append(f"N{n} {c}->{c} k2d2 + {3 * c}->{c} k1 fused {h}x{w}")
     return out
 
@@ -240,7 +242,9 @@ def head_mc_h8(x: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor
     # layer-granular accounting: the head conv reads its fp16 input and "writes" fp32 logits; the epilogue of SURVEY 8(d) reads them back
     flops = 2.0 * 8 * g * classes * n * h * w
     nbytes = n * h * w * (2.0 * 8 * g + 4.0 * classes) + 2.0 * classes * 8 * g
-    ops.TIMING.append((f"head_mc_h8_kernel<{g // 2}>", flops, nbytes, e0, e1))
+    # what the fused kernel must move: the decoder output of every pass in, p_bar / H / MI / argmax of every scan out
+    min_bytes = n * h * w * 2.0 * 8 * g + batch * h * w * (4.0 * classes + 16.0) + 2.0 * classes * 8 * g
+    ops.TIMING.append((f"head_mc_h8_kernel<{g // 2}>", flops, nbytes, e0, e1, min_bytes))
     ops.TIMING_TAGS.append(f"N{n} {8 * g}->{classes} k1 head + MC reduce T={passes} {h}x{w}")
     return p_bar, hn, mi, preds
 

@@ -1,12 +1,15 @@
 """Mirror of the reference's ``ECEAggregator`` (src/metrics/ece.py:13-212), top-label ECE / MCE.
 
-Same constructor, ``update(preds, labels)``, ``compute(save_plot_path, title, dpi)`` and ``reset``.
-The per-pixel work (re-normalise, max over classes, correctness, 15-bin histogram with the
-reference's float32 ``linspace`` edges) is one HIP kernel that adds into three per-bin device
-accumulators, so nothing is copied to the host per batch.  Consequences, both stated in DESIGN.md:
-the bins are EXACT over all pixels seen (the reference's reservoir sub-sample once more than
-``max_samples`` pixels were seen is not reproduced; below the cap the results coincide), and only
-``binning='uniform'`` is supported on the device path.
+Same constructor, ``update(preds, labels)``, ``compute(save_plot_path, title, dpi)`` and ``reset``; nothing is copied to the host
+per batch.  Two accumulation forms, chosen by the constructor arguments exactly as the reference's semantics require:
+
+* ``max_samples=None`` and ``binning='uniform'`` (the reference keeps EVERY valid pixel, ece.py:88-91): the per-pixel work
+  (re-normalise, max over classes, correctness, histogram over the reference's float32 ``linspace`` edges) is one HIP kernel that
+  adds into three per-bin device accumulators -- identical bins without storing the samples.
+* ``max_samples=N`` (the Trainer's 500 000, trainer.py:215-222) or ``binning='adaptive'``: the (confidence, correct) samples stay in
+  device buffers under the reference's reservoir policy (ece.py:93-111) -- the numpy ``default_rng(seed)`` draws are made on the host
+  in the reference's order (``_reservoir.CappedColumns``) and applied to the device columns -- and are binned at ``compute()`` over
+  uniform or equal-mass edges (ece.py:115-128; the quantiles are taken by numpy on a host copy of the <= N confidences).
 """
 from __future__ import annotations
 
@@ -15,6 +18,7 @@ import pandas as pd
 import torch
 
 from semanticlidarunc_amd import ops
+from semanticlidarunc_amd._reservoir import CappedColumns
 
 
 class ECEAggregator:
@@ -24,16 +28,30 @@ class ECEAggregator:
         assert plot_style in {"classic", "classic+hist", "gap"}
         assert mode in {"alpha", "logits", "probs"}
         assert n_bins >= 2
-        if binning != "uniform":
-            raise NotImplementedError("adaptive (equal-mass) binning needs the raw confidences; only 'uniform' runs on the device")
         self.n_bins, self.mode, self.ignore_index = int(n_bins), mode, ignore_index
         self.max_samples, self.eps = max_samples, float(eps)
         self.binning, self.plot_style = binning, plot_style
+        self._keeps_samples = max_samples is not None or binning != "uniform"
+        self._buf = CappedColumns(max_samples, seed)       # columns: confidence fp32, correct uint8 (device); sample form only
         self.reset()
+
+    # the reference's attribute names, for code that inspects the aggregator
+    @property
+    def rng(self):
+        return self._buf.rng
+
+    @property
+    def _conf(self):
+        return torch.empty(0, dtype=torch.float32) if self._buf.columns is None else self._buf.columns[0]
+
+    @property
+    def _correct(self):
+        return torch.empty(0, dtype=torch.bool) if self._buf.columns is None else self._buf.columns[1].bool()
 
     def reset(self):
         self._count = self._sum_correct = self._sum_conf = None
         self._seen = 0
+        self._buf.clear()
 
     def _ensure(self, device):
         if self._count is None:
@@ -48,28 +66,107 @@ class ECEAggregator:
         if not preds.is_cuda:
             raise RuntimeError("ECEAggregator.update: predictions must be on the GPU (no CPU fallback)")
         p = preds.detach().float().contiguous()
+        lab = labels.to(p.device).to(torch.int64).contiguous()
+        if self._keeps_samples:
+            conf, flag = ops.ece_samples(p, lab, self.mode, self.ignore_index, self.eps)
+            keep = flag != 2                                  # boolean-mask order == the reference's NCHW scan order
+            self._buf.push(conf[keep], flag[keep])
+            self._seen = self._buf.seen
+            return
         if self.mode == "logits":
             p, _, _ = ops.softmax_entropy(p)
         # 'alpha' and 'probs' are both "non-negative scores normalised by their sum"
         self._ensure(p.device)
-        lab = labels.to(p.device).to(torch.int64).contiguous()
         ops.ece_update(p, lab, self._count, self._sum_correct, self._sum_conf, self.ignore_index)
+
+    def _bin_edges(self) -> np.ndarray:
+        """ece.py:115-128: float32 linspace, or equal-mass edges from the empirical quantiles of the stored confidences."""
+        uniform = np.linspace(0.0, 1.0, self.n_bins + 1, dtype=np.float32)
+        edges = uniform
+        if self.binning == "adaptive" and len(self._buf) > 0:
+            q = np.linspace(0.0, 1.0, self.n_bins + 1, dtype=np.float32)
+            edges = np.quantile(self._buf.columns[0].cpu().numpy(), q)
+            edges[0], edges[-1] = 0.0, 1.0
+            edges = np.unique(edges)
+            if edges.size < self.n_bins + 1:
+                edges = uniform
+        edges[0], edges[-1] = 0.0, 1.0
+        return edges
+
+    def _bins(self):
+        """(edges, n int, sum_correct f64, sum_conf f64) or None when nothing was seen."""
+        if self._keeps_samples:
+            if len(self._buf) == 0:
+                return None
+            edges = self._bin_edges()
+            conf, ok = self._buf.columns
+            dev_edges = torch.from_numpy(np.ascontiguousarray(edges, dtype=np.float32)).to(conf.device)
+            n, n_ok, s_conf = ops.binned_stats(conf.contiguous(), ok.contiguous(), dev_edges)
+            return edges, n.cpu().numpy().astype(int), n_ok.cpu().numpy().astype(np.float64), s_conf.cpu().numpy()
+        if self._count is None:
+            return None
+        edges = np.linspace(0.0, 1.0, self.n_bins + 1, dtype=np.float32)
+        edges[0], edges[-1] = 0.0, 1.0
+        return edges, self._count.cpu().numpy().astype(int), self._sum_correct.cpu().numpy(), self._sum_conf.cpu().numpy()
 
     def _stats_df(self) -> pd.DataFrame:
         cols = ["low", "high", "center", "width", "n", "pct", "acc", "conf"]
-        if self._count is None:
+        bins = self._bins()
+        if bins is None or bins[1].sum() == 0:
             return pd.DataFrame(columns=cols)
-        n = self._count.cpu().numpy().astype(int)
-        if n.sum() == 0:
-            return pd.DataFrame(columns=cols)
-        acc_s, conf_s = self._sum_correct.cpu().numpy(), self._sum_conf.cpu().numpy()
-        edges = np.linspace(0.0, 1.0, self.n_bins + 1, dtype=np.float32)
-        edges[0], edges[-1] = 0.0, 1.0
-        acc = np.divide(acc_s, n, out=np.full(self.n_bins, np.nan), where=n > 0)
-        conf = np.divide(conf_s, n, out=np.full(self.n_bins, np.nan), where=n > 0)
+        edges, n, acc_s, conf_s = bins
+        k = n.size
+        acc = np.divide(acc_s, n, out=np.full(k, np.nan), where=n > 0)
+        conf = np.divide(conf_s, n, out=np.full(k, np.nan), where=n > 0)
         lows, highs = edges[:-1], edges[1:]
+        total = len(self._buf) if self._keeps_samples else int(n.sum())
         return pd.DataFrame({"low": lows, "high": highs, "center": 0.5 * (lows + highs), "width": highs - lows,
-                             "n": n, "pct": 100.0 * n / max(1, int(n.sum())), "acc": acc, "conf": conf})
+                             "n": n, "pct": 100.0 * n / max(1, total), "acc": acc, "conf": conf})
+
+    @torch.no_grad()
+    def merge_across_ranks(self, group=None) -> None:
+        """Data-parallel evaluation: make every rank hold the union of all ranks' evidence.  Bin form: three
+        all-reduces.  Sample form: the columns are all-gathered in rank order; if their union exceeds ``max_samples`` a uniformly
+        drawn subset is kept (the reference has no multi-process form to follow here)."""
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        world = dist.get_world_size(group)
+        if not self._keeps_samples:
+            if self._count is None:
+                raise RuntimeError("merge_across_ranks: call on a device (see _ensure) -- a rank that saw no batch must still join the collective")
+            for t in (self._count, self._sum_correct, self._sum_conf):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return
+        dev = self._merge_device
+        mine = len(self._buf)
+        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        sizes[dist.get_rank(group)] = mine
+        dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
+        seen = torch.tensor([self._buf.seen], dtype=torch.int64, device=dev)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM, group=group)
+        cap = int(sizes.max())
+        if cap == 0:
+            return
+        cols = []
+        for ci, dt in ((0, torch.float32), (1, torch.uint8)):
+            pad = torch.zeros(cap, dtype=dt, device=dev)
+            if mine:
+                pad[:mine] = self._buf.columns[ci]
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad, group=group)
+            cols.append(torch.cat([p[:int(k)] for p, k in zip(parts, sizes.tolist())]))
+        if self.max_samples is not None and cols[0].numel() > self.max_samples:
+            pick = torch.from_numpy(self._buf.rng.choice(cols[0].numel(), size=self.max_samples, replace=False)).to(dev)
+            cols = [c[pick] for c in cols]
+        self._buf.columns, self._buf.seen = cols, int(seen.item())
+        self._seen = self._buf.seen
+
+    @property
+    def _merge_device(self):
+        if self._buf.columns is not None:
+            return self._buf.columns[0].device
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
     def compute(self, save_plot_path: str | None = None, title: str = "Reliability Diagram", dpi: int = 200):
         """((ece, mce), stats_df, fig) -- fig is None unless save_plot_path is given; an empty

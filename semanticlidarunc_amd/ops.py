@@ -31,6 +31,10 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
     if not t.is_cuda:
         raise RuntimeError(f"{name}: tensor is on '{t.device}'; the HIP path only runs on a GPU (no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        # launches go to the CURRENT device's stream; a tensor living on another GPU would be dereferenced there
+        raise RuntimeError(f"{name}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device(local_rank) (distributed.init_from_env does) or use `with torch.cuda.device(t.device)`")
     if t.dtype != dtype:
         raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
     if not t.is_contiguous():
@@ -453,6 +457,11 @@ def bn_coeffs_fwd(sums, count: float, gamma, beta, eps: float, momentum: float, 
     check(_lib.load().slu_bn_coeffs_fwd(_ptr(s), _ptr(q), float(count), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
                                         1 if train else 0, _ptr(running_mean), _ptr(running_var), c, out[0].data_ptr(), out[1].data_ptr(),
                                         out[2].data_ptr(), out[3].data_ptr(), _stream()), "slu_bn_coeffs_fwd")
+    if train and running_mean is not None:
+        # the kernel wrote the running statistics through raw pointers: tell torch, so that caches keyed on tensor versions
+        # (salsanext._tkey: folded eval-BatchNorm coefficients) see the change
+        torch.autograd.graph.increment_version(running_mean)
+        torch.autograd.graph.increment_version(running_var)
     return out[0], out[1], out[2], out[3]
 
 
@@ -729,6 +738,39 @@ def binned_counts(u: torch.Tensor, correct: torch.Tensor, edges: torch.Tensor):
     check(_lib.load().slu_binned_counts(u.data_ptr(), correct.data_ptr(), u.numel(), edges.data_ptr(), k, cnt.data_ptr(), ok.data_ptr(), _stream()),
           "slu_binned_counts")
     return cnt, ok
+
+
+def ece_samples(preds: torch.Tensor, labels: torch.Tensor, mode: str, ignore_index=None, eps: float = 1e-12):
+    """(conf fp32 [B,H,W] in [0,1], flag uint8 [B,H,W]: 1 correct / 0 wrong / 2 ignored) -- slu_ece_samples (metrics/ece.py:55-84)."""
+    _req(preds, "preds")
+    _req(labels, "labels", torch.int64)
+    if preds.dim() != 4 or tuple(labels.shape) != (preds.shape[0], preds.shape[2], preds.shape[3]):
+        raise RuntimeError(f"ece_samples: preds [B,C,H,W] / labels [B,H,W] expected, got {tuple(preds.shape)} / {tuple(labels.shape)}")
+    if mode not in AUROC_MODES:
+        raise ValueError(f"ece_samples: unknown mode {mode!r}")
+    b, c, h, w = preds.shape
+    conf = torch.empty((b, h, w), dtype=torch.float32, device=preds.device)
+    flag = torch.empty((b, h, w), dtype=torch.uint8, device=preds.device)
+    check(_lib.load().slu_ece_samples(preds.data_ptr(), labels.data_ptr(), b, c, h * w, AUROC_MODES[mode], 0 if ignore_index is None else 1,
+                                      0 if ignore_index is None else int(ignore_index), float(eps), conf.data_ptr(), flag.data_ptr(), _stream()),
+          "slu_ece_samples")
+    return conf, flag
+
+
+def binned_stats(u: torch.Tensor, correct: torch.Tensor, edges: torch.Tensor):
+    """The three np.histogram calls of metrics/ece.py:136-140 on the device: (count int64 [K], n_correct int64 [K], sum_u float64 [K])."""
+    _req(u, "u")
+    _req(correct, "correct", torch.uint8)
+    _req(edges, "edges")
+    if u.dim() != 1 or u.shape != correct.shape or u.numel() == 0 or edges.dim() != 1 or not 2 <= edges.numel() <= 257:
+        raise RuntimeError("binned_stats: 1-D samples and 2..257 edges expected")
+    k = edges.numel() - 1
+    cnt = torch.zeros(k, dtype=torch.int64, device=u.device)
+    ok = torch.zeros(k, dtype=torch.int64, device=u.device)
+    su = torch.zeros(k, dtype=torch.float64, device=u.device)
+    check(_lib.load().slu_binned_stats(u.data_ptr(), correct.data_ptr(), u.numel(), edges.data_ptr(), k, cnt.data_ptr(), ok.data_ptr(), su.data_ptr(),
+                                       _stream()), "slu_binned_stats")
+    return cnt, ok, su
 
 
 # ------------------------------------------------------------------------------------------------

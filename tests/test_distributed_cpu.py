@@ -103,3 +103,78 @@ def test_single_process_is_a_no_op():
         assert (a is None and p.grad is None) or torch.equal(a, p.grad)
     s = ShardedSampler(10, 0, 1, shuffle=False)
     assert list(iter(s)) == list(range(10)) and len(s) == 10
+
+
+def _metrics_worker(rank, world, port, out):
+    """Uneven evidence: rank 1 saw NO batch (unallocated accumulators) -- it must still enter every collective."""
+    from semanticlidarunc_amd.metrics.ece import ECEAggregator
+    from semanticlidarunc_amd.models.evaluator import IoUEvaluator
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    init_from_env("gloo")
+    cpu = torch.device("cpu")
+    iou, ece_bins, ece_samples = IoUEvaluator(3), ECEAggregator(n_bins=4, mode="probs"), ECEAggregator(n_bins=4, mode="probs", max_samples=5)
+    if rank == 0:
+        iou._ensure(cpu)
+        iou.confmat += torch.arange(9).reshape(3, 3)
+        ece_bins._ensure(cpu)
+        ece_bins._count += torch.tensor([1, 2, 3, 4])
+        ece_samples._buf.push(torch.tensor([0.1, 0.2, 0.3]), torch.tensor([1, 0, 1], dtype=torch.uint8))
+    all_reduce_metrics(iou, ece_bins, device=cpu)
+    all_reduce_metrics(None, ece_samples, device=cpu)
+    assert torch.equal(iou.confmat, torch.arange(9).reshape(3, 3)) and ece_bins._count.tolist() == [1, 2, 3, 4]
+    assert ece_samples._conf.tolist() == torch.tensor([0.1, 0.2, 0.3]).tolist() and ece_samples._seen == 3
+    # evaluation sharding keeps every sample: 7 samples over 2 ranks -> 3 + 4, disjoint, in order
+    mine = list(ShardedSampler(7, rank, world, shuffle=False, drop_last=False))
+    assert mine == ([0, 1, 2] if rank == 0 else [3, 4, 5, 6]) and len(ShardedSampler(7, rank, world, drop_last=False)) == len(mine)
+    assert len(list(ShardedSampler(7, rank, world, shuffle=False))) == 3          # training default: equal shards, tail dropped
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_metric_reduction_with_an_empty_rank_and_uneven_eval_shards():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metrics_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def test_bench_gpus_n_launches_n_ranks_and_refuses_a_mismatch():
+    """`python bench.py --gpus 2` with no torchrun environment must start 2 ranks itself (stub step: gloo on the CPU, no GPU or HIP
+    library touched) and print ONE line with n_gpus == the communicator's world size == 2; a WORLD_SIZE that disagrees with --gpus
+    must exit non-zero instead of printing a line for a different rank count."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-cpu"], env=_clean_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    # one rank, plainly
+    r1 = subprocess.run([sys.executable, bench, "--stub-cpu", "--steps", "2", "--warmup", "0"], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert r1.returncode == 0 and json.loads(r1.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    # torchrun environment that disagrees with --gpus
+    env = _clean_env()
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--stub-cpu"], env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+    bad2 = subprocess.run([sys.executable, bench, "--gpus", "1", "--stub-cpu"], env=dict(env, WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
+    assert bad2.returncode != 0

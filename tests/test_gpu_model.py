@@ -133,3 +133,35 @@ def test_shared_prefix_mc_forward_equals_full_passes(cuda, model):
     with pytest.raises(RuntimeError):
         model.forward_mc(x, 2)
     model.eval()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+def test_eval_after_running_stat_update_with_frozen_affine_matches_oracle(cuda, precision):
+    """BatchNorm re-calibration: train-mode forwards under no_grad change ONLY the running statistics (no optimizer step bumps a
+    parameter version).  The next eval forward must fold the NEW statistics (the folded-BN cache is keyed on tensor versions, which
+    the raw-pointer update inside slu_bn_coeffs_fwd now bumps), i.e. agree with the oracle evaluated on the updated state_dict."""
+    from semanticlidarunc_amd import salsanext as sn
+    m = seeded_model(SalsaNext).to(cuda)
+    x, _ = synthetic_scan(2, 32, 128, seed=21)
+    xg = x.to(cuda)
+    sn.set_conv_precision(precision)
+    try:
+        with torch.no_grad():
+            before = m(xg).cpu()                          # fills the folded-BN caches
+            m.train()
+            set_dropout_mode(m, False)                    # statistics only: keep the forward deterministic
+            m(xg)
+            m.eval()
+            got = m(xg).cpu()
+            sd = {k: v.cpu() for k, v in m.state_dict().items()}
+            want = osalsa.salsanext_forward(sd, x)
+    finally:
+        sn.set_conv_precision("fp32")
+    assert float((before - want).abs().max()) > 10 * TOL          # the statistics really moved
+    assert float((got - want).abs().max()) <= TOL
+    # distributed.average_buffers / broadcast_parameters write in place on the tensors themselves; same invalidation path
+    with torch.no_grad():
+        for b in m.buffers():
+            if b.is_floating_point():
+                b.mul_(1.0)
+        assert float((m(xg).cpu() - want).abs().max()) <= TOL

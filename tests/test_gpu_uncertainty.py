@@ -119,3 +119,37 @@ def test_ece_bins_match_reference(cuda):
     agg2 = ECEAggregator(n_bins=15, mode="logits", ignore_index=0)
     agg2.update(torch.log(_t(g["probs"])).to(cuda), _t(g["labels"]).to(cuda))
     assert np.array_equal(agg2.compute()[1]["n"].to_numpy(), g["n"])
+
+
+def _ece_batches(x, lab):
+    return [(x, lab), (x.flip(0), lab.flip(0)), (x.roll(1, 3), lab.roll(1, 2)), (x.flip(3), lab.flip(2))]
+
+
+@pytest.mark.parametrize("mode", ["probs", "logits", "alpha"])
+@pytest.mark.parametrize("cap,binning", [(3000, "uniform"), (None, "adaptive"), (2500, "adaptive")])
+def test_ece_reservoir_and_adaptive_binning_match_reference(cuda, mode, cap, binning):
+    """a14 beyond the cap: the reference's numpy-seeded reservoir (metrics/ece.py:93-111) and equal-mass bins (:115-128) on device
+    buffers; golden from the reference itself (tools/gen_golden_r02.py).  Confidences may differ from the CPU's in the last bit."""
+    g = golden("ece_capped_adaptive_2x20x16x64")
+    tag = f"{mode}|{cap}|{binning}"
+    agg = ECEAggregator(n_bins=15, mode=mode, ignore_index=0, max_samples=cap, seed=0, binning=binning)
+    x, lab = torch.from_numpy(g[mode]).to(cuda), torch.from_numpy(g["labels"]).to(cuda)
+    for xb, lb in _ece_batches(x, lab):
+        agg.update(xb.contiguous(), lb.contiguous())
+    assert agg._seen == int(g["seen:" + tag]) and agg._conf.numel() == int(g["kept:" + tag])
+    conf = np.sort(agg._conf.cpu().numpy())
+    assert np.abs(conf - g["conf_sorted:" + tag]).max() <= 2e-7                   # the same samples survived the same draws
+    assert int(agg._correct.sum()) == int(g["ncorrect:" + tag])
+    (e, m), stats, _ = agg.compute()
+    assert np.abs(stats["low"].to_numpy() - g["edges:" + tag][:-1]).max() <= 2e-7
+    assert int(np.abs(stats["n"].to_numpy() - g["n:" + tag]).sum()) <= 4           # a last-bit confidence on a bin edge
+    assert abs(e - float(g["ece:" + tag])) <= 2e-4 and abs(m - float(g["mce:" + tag])) <= 5e-3
+
+
+def test_ece_adaptive_falls_back_to_uniform_edges_on_duplicate_quantiles(cuda):
+    g = golden("ece_capped_adaptive_2x20x16x64")
+    agg = ECEAggregator(n_bins=15, mode="probs", ignore_index=0, binning="adaptive")
+    agg.update(torch.from_numpy(g["onehot_probs"]).to(cuda), torch.from_numpy(g["onehot_labels"]).to(cuda))
+    (e, _), stats, _ = agg.compute()
+    assert np.array_equal(stats["low"].to_numpy(), np.linspace(0, 1, 16, dtype=np.float32)[:-1])
+    assert abs(e - float(g["ece:onehot_adaptive"])) <= 1e-6

@@ -290,3 +290,28 @@ def test_spherical_projection_golden_and_known_answers():
     img, _, _, _ = oproj.spherical_projection(pts, 4, 8, theta_range=[-0.5, 0.5])
     assert np.count_nonzero(img[..., 0] != 0) + np.count_nonzero(img[..., 1] != 0) == 2
     assert float(img[..., 3].max()) == np.float32(0.9) and 7.0 in img[..., 4] and 3.0 not in img[..., 4]
+
+
+def _ece_batches(x, lab):
+    return [(x, lab), (np.flip(x, 0), np.flip(lab, 0)), (np.roll(x, 1, 3), np.roll(lab, 1, 2)), (np.flip(x, 3), np.flip(lab, 2))]
+
+
+def test_ece_reservoir_and_adaptive_binning_match_reference():
+    """metrics/ece.py:93-128 (golden: tools/gen_golden_r02.py): buffers after the seeded reservoir, equal-mass edges, bins, ECE / MCE."""
+    g = golden("ece_capped_adaptive_2x20x16x64")
+    for mode in ("probs", "logits", "alpha"):
+        for cap, binning in ((3000, "uniform"), (None, "adaptive"), (2500, "adaptive")):
+            tag = f"{mode}|{cap}|{binning}"
+            buf = ometrics.ECESamples(cap, seed=0)
+            for xb, lb in _ece_batches(g[mode], g["labels"]):
+                buf.update(*ometrics.top_label(np.ascontiguousarray(xb), np.ascontiguousarray(lb), 0, mode))
+            assert buf.seen == int(g["seen:" + tag]) and buf.conf.size == int(g["kept:" + tag])
+            assert np.array_equal(np.sort(buf.conf), g["conf_sorted:" + tag]) and int(buf.correct.sum()) == int(g["ncorrect:" + tag])
+            edges = ometrics.ece_edges(buf.conf, 15, binning)
+            assert np.array_equal(edges, g["edges:" + tag])
+            n, acc_s, conf_s = ometrics.ece_bins_over(buf.conf, buf.correct, edges)
+            assert np.array_equal(n, g["n:" + tag])
+            e, m = ometrics.ece_from_bins(n, acc_s, conf_s)
+            assert abs(e - float(g["ece:" + tag])) <= 1e-7 and abs(m - float(g["mce:" + tag])) <= 1e-7
+    c, _ = ometrics.top_label(g["onehot_probs"], g["onehot_labels"], 0, "probs")
+    assert np.array_equal(ometrics.ece_edges(c, 15, "adaptive"), np.linspace(0, 1, 16, dtype=np.float32))   # duplicate quantiles -> uniform

@@ -21,6 +21,68 @@ from semanticlidarunc_amd.salsanext import SalsaNext  # noqa: E402
 from semanticlidarunc_amd.testing import seeded_model, synthetic_scan  # noqa: E402
 
 
+def measure(dev, batch=4, steps=5, warmup=2, height=64, width=2048, precision="fp32", graph=False, rank=0, world=1):
+    """Time `steps` training steps on `dev` (after `warmup`): returns the JSON-able result dict.  Used by main() below and by
+    bench.py's `train_step` block (BASELINE configs[1]: batch 4 of 64x2048, fp32, one GPU)."""
+    from semanticlidarunc_amd import salsanext as sn
+    prev = sn._TRAIN_CONV_PRECISION
+    sn.set_train_conv_precision(precision)
+    try:
+        model = seeded_model(SalsaNext).to(dev).train()
+        broadcast_parameters(model)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, capturable=graph)
+        red = FlatGradAllReduce(model.parameters())
+        if not graph:
+            red.attach_to_optimizer(opt)
+        x, y = synthetic_scan(batch, height, width, seed=1234 + rank)
+        x, y = x.to(dev), y.to(dev)
+        torch.manual_seed(7 + rank)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss, nll, ls = salsanext_loss(model(x), y, 1.0, 1.0, 0)
+            loss.backward()
+            opt.step()
+            return loss
+
+        def sync():
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            step()
+        sync()
+        if graph:
+            from semanticlidarunc_amd.graph_step import GraphedTrainStep
+            graphed = GraphedTrainStep(model, opt, lambda out, t: salsanext_loss(out, t, 1.0, 1.0, 0)[0], x, y,
+                                       reducer=red if world > 1 else None)      # multi-GPU: the all-reduce + update follow the replay
+            run = lambda: graphed(x, y)
+        else:
+            run = step
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = run()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        ms = dt / steps * 1e3
+        flops = 3 * 124.60e9 * batch * (height * width) / (64 * 2048)
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"metric": "training scans/s (fwd + NLL/Lovasz loss + bwd + AdamW)", "value": round(batch * world * steps / dt, 3),
+                "unit": "scans/s", "n_gpus": world, "ms_per_step": round(ms, 2), "batch_per_gpu": batch, "shape": f"{height}x{width}x5",
+                "steps": steps, "warmup": warmup,
+                "dtype": "f32" if precision == "fp32" else "f32 storage + accumulate, f16x3 products in the forward convs; exact f32 dgrad / wgrad",
+                "conv_tflops_per_gpu(3x fwd flops)": round(tf, 2), "frac_fp32_mfma_peak": round(tf / 157.3, 4), "loss": round(float(loss), 5),
+                "grad_allreduce_mb": round(red.nbytes / 1e6, 1), "hip_graph": bool(graph)}
+    finally:
+        sn.set_train_conv_precision(prev)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
@@ -37,57 +99,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rank, _, world = init_from_env(device=dev)
-    from semanticlidarunc_amd import salsanext as sn
-    sn.set_train_conv_precision(a.precision)
-    model = seeded_model(SalsaNext).to(dev).train()
-    broadcast_parameters(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, capturable=a.graph)
-    red = FlatGradAllReduce(model.parameters())
-    if not a.graph:
-        red.attach_to_optimizer(opt)
-    x, y = synthetic_scan(a.batch, a.height, a.width, seed=1234 + rank)
-    x, y = x.to(dev), y.to(dev)
-    torch.manual_seed(7 + rank)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss, nll, ls = salsanext_loss(model(x), y, 1.0, 1.0, 0)
-        loss.backward()
-        opt.step()
-        return loss
-
-    def sync():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    sync()
-    if a.graph:
-        from semanticlidarunc_amd.graph_step import GraphedTrainStep
-        graphed = GraphedTrainStep(model, opt, lambda out, t: salsanext_loss(out, t, 1.0, 1.0, 0)[0], x, y,
-                                   reducer=red if world > 1 else None)      # multi-GPU: the all-reduce + update follow the replay
-        run = lambda: graphed(x, y)
-    else:
-        run = step
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = run()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    out = measure(dev, a.batch, a.steps, a.warmup, a.height, a.width, a.precision, a.graph, rank, world)
     if rank == 0:
-        ms = dt / a.steps * 1e3
-        flops = 3 * 124.60e9 * a.batch * (a.height * a.width) / (64 * 2048)
-        print(json.dumps({"metric": "training scans/s (fwd + loss + bwd + AdamW)", "value": round(a.batch * world * a.steps / dt, 3),
-                          "unit": "scans/s", "n_gpus": world, "ms_per_step": round(ms, 2), "batch_per_gpu": a.batch, "dtype": "f32" if a.precision == "fp32" else "f32 storage + accumulate, f16x3 products in the forward convs; exact f32 dgrad / wgrad",
-                          "conv_tflops_per_gpu(3x fwd flops)": round(flops / (ms * 1e-3) / 1e12, 2), "loss": round(float(loss), 5),
-                          "grad_allreduce_mb": round(red.nbytes / 1e6, 1), "hip_graph": bool(a.graph)}))
+        print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
 
