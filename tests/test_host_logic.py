@@ -91,5 +91,11 @@ def test_ece_compute_from_injected_bins_and_empty_case():
     (e, m), stats, fig = agg.compute()
     assert fig is None and list(stats["n"]) == [0, 10, 0, 30]
     assert abs(e - (10 / 40 * 0.1 + 30 / 40 * 0.05)) < 1e-12 and abs(m - 0.1) < 1e-12
-    with pytest.raises(NotImplementedError):
-        ECEAggregator(binning="adaptive")
+    # the sample-keeping forms (reservoir cap / equal-mass bins, metrics/ece.py:93-128) are constructible and start empty
+    for kw in ({"binning": "adaptive"}, {"max_samples": 10}):
+        agg = ECEAggregator(n_bins=4, mode="probs", **kw)
+        assert agg._keeps_samples and agg._conf.numel() == 0 and agg._seen == 0
+        (e, m), stats = agg.compute()
+        assert np.isnan(e) and stats.empty
+    with pytest.raises(AssertionError):
+        ECEAggregator(binning="quantile")

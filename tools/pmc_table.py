@@ -41,8 +41,9 @@ def load(d):
 def main():
     rows = OrderedDict()
     counters = []
-    args = [a for a in sys.argv[1:] if not a.startswith("--json=")]
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
     json_out = next((a[len("--json="):] for a in sys.argv[1:] if a.startswith("--json=")), None)
+    meta_images = next((int(a[len("--meta-images="):]) for a in sys.argv[1:] if a.startswith("--meta-images=")), None)
     for d in args:
         dur, name, vals = load(d)
         ids = sorted(dur)
@@ -77,6 +78,15 @@ def main():
             for key in list(a):
                 if key != "launches":
                     a[key] = a[key] / n
+        if meta_images is not None:
+            # bench.py attaches these numbers only to the build of libslu_hip.so they were measured with
+            import hashlib
+            lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "semanticlidarunc_amd", "libslu_hip.so")
+            agg["_meta"] = {"images": meta_images, "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+                            "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace -- python3 tools/prof_forward.py "
+                                       f"{meta_images} 2 mc with SLU_CONV_PRECISION=f16 (the launches of one default bench.py step)",
+                            "units": "FETCH_SIZE / WRITE_SIZE in KB per launch (average over the launches of the last MC step); gfx950: double "
+                                     "FETCH_SIZE for 16 B/lane loads (MI355X_MICROARCH.md, HBM)"}
         with open(json_out, "w") as f:
             json.dump(agg, f, indent=1, sort_keys=True)
     print("dur_us " + " ".join(counters) + " kernel")
