@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 15
+#define SLU_ABI_VERSION 16
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -308,6 +308,25 @@ typedef struct slu_conv_tail_h8_desc {   /* HOST struct */
 } slu_conv_tail_h8_desc;
 int slu_conv_tail_h8_supported(int C, int H, int W);
 int slu_conv_tail_h8_fwd(const slu_conv_tail_h8_desc* desc, slu_stream_t stream);
+
+/* Fused ResContextBlock on the h8 path (SalsaNext.py:10-39: conv1 1x1 + act -> shortcut; conv2 3x3 + act + bn1; conv3 3x3 dil 2 +
+ * act + bn2; + shortcut), the three full-resolution blocks at the head of the network:
+ *   s = act(conv1x1(x) + bias1);  a1 = bn1(act(conv3x3_pad1(s) + bias2));  out = s + bn2(act(conv3x3_dil2_pad2(a1) + bias3))
+ * s and a1 stay on chip (rounded to fp16 exactly where the three separate slu_conv2d_h8_fwd launches would store them).
+ * x: h8 [N][ceil(Cin/8)][H][W][8]; out: h8 [N][4][H][W][8]; w1 / w2 / w3 = slu_pack_conv_weight_h8 of [32][Cin][1][1] / [32][32][3][3] /
+ * [32][32][3][3]; act = LeakyReLU(slope), 0 <= slope <= 1.  Cin <= 32, C == 32 (slu_ctx_block_h8_supported). */
+typedef struct slu_ctx_block_h8_desc {   /* HOST struct */
+  const void* x;
+  int32_t N, H, W, Cin, C;
+  const void *w1, *w2, *w3;
+  const float* bias1;                    /* [32] fp32 or NULL */
+  const float *bias2, *bn1_a, *bn1_b;
+  const float *bias3, *bn2_a, *bn2_b;
+  float slope;
+  void* out;
+} slu_ctx_block_h8_desc;
+int slu_ctx_block_h8_supported(int Cin, int C, int H, int W);
+int slu_ctx_block_h8_fwd(const slu_ctx_block_h8_desc* desc, slu_stream_t stream);
 
 /* Segmentation head + MC-dropout reduction in one pass on the h8 path (SalsaNext.py:213 + trainer.py:1143-1154):
  * x: h8 [T*B][G][HW][8], pass-major (image t*B + b = pass t of scan b), 8 G = input channels of the head (G in {2, 4, 8});

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -69,6 +69,19 @@ class ConvTailH8Desc(C.Structure):
         ("biasB", C.c_void_p), ("bnB_a", C.c_void_p), ("bnB_b", C.c_void_p),
         ("hasactB", C.c_int32), ("slopeB", C.c_float),
         ("resid", C.c_void_p), ("out", C.c_void_p),
+    ]
+
+
+class CtxBlockH8Desc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("C", C.c_int32),
+        ("w1", C.c_void_p), ("w2", C.c_void_p), ("w3", C.c_void_p),
+        ("bias1", C.c_void_p),
+        ("bias2", C.c_void_p), ("bn1_a", C.c_void_p), ("bn1_b", C.c_void_p),
+        ("bias3", C.c_void_p), ("bn2_a", C.c_void_p), ("bn2_b", C.c_void_p),
+        ("slope", C.c_float),
+        ("out", C.c_void_p),
     ]
 
 
@@ -152,6 +165,8 @@ SIGNATURES = {
                                          c_stream]),
     "slu_dirichlet_loss_bwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int64, c_f32p, c_f32p,
                                          c_stream]),
+    "slu_ctx_block_h8_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "slu_ctx_block_h8_fwd": (C.c_int, [C.POINTER(CtxBlockH8Desc), c_stream]),
     "slu_conv_tail_h8_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "slu_conv_tail_h8_fwd": (C.c_int, [C.POINTER(ConvTailH8Desc), c_stream]),
     "slu_head_mc_h8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_f32p, C.c_int, C.c_float, c_f32p, c_f32p, c_f32p,

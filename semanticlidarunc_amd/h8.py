@@ -210,6 +210,57 @@ def conv_tail_h8(a1: torch.Tensor, a2: torch.Tensor, w2x2: torch.Tensor, w1x1: t
     return out
 
 
+def ctx_block_supported(cin: int, c: int, h: int, w: int) -> bool:
+    return bool(_lib.load().slu_ctx_block_h8_supported(int(cin), int(c), int(h), int(w)))
+
+
+def ctx_block_h8(x: torch.Tensor, cin: int, w1: torch.Tensor, w2: torch.Tensor, w3: torch.Tensor, bias1: Optional[torch.Tensor],
+                 bias2: Optional[torch.Tensor], bn1: Optional[tuple], bias3: Optional[torch.Tensor], bn2: Optional[tuple],
+                 slope: float) -> torch.Tensor:
+    """One fused ResContextBlock (slu_ctx_block_h8_fwd, SalsaNext.py:25-39):
+        s = leaky(conv1x1(x) + bias1);  a1 = bn1(leaky(conv3x3(s) + bias2));  out = s + bn2(leaky(conv3x3_dil2(a1) + bias3))
+    x: h8 [N, ceil(cin/8), H, W, 8]; w1 / w2 / w3: pack_conv_weight_h8 of [32, cin, 1, 1] / [32, 32, 3, 3] / [32, 32, 3, 3]; bn*: (scale, shift)."""
+    lib = _lib.load()
+    _req_h8(x, "x")
+    n, g, h, w, _ = x.shape
+    if not 8 * (g - 1) < cin <= 8 * g or not ctx_block_supported(cin, 32, h, w):
+        raise RuntimeError(f"ctx_block_h8: cin={cin} with {g} input blocks is not covered by the fused kernel")
+    for t, nme, shape in ((w1, "w1", (32, cin, 1)), (w2, "w2", (32, 32, 3)), (w3, "w3", (32, 32, 3))):
+        _req(t, nme, torch.uint8)
+        if t.numel() != lib.slu_packed_weight_bytes_h8(*shape):
+            raise RuntimeError(f"{nme}: packed weight size does not match {shape}")
+    vecs = (("bias1", bias1), ("bias2", bias2), ("bias3", bias3)) + tuple((f"bn{k}[{i}]", v) for k, pair in ((1, bn1), (2, bn2)) if pair is not None
+                                                                           for i, v in enumerate(pair))
+    for name, t in vecs:
+        if t is not None:
+            _req(t, name)
+            if t.numel() != 32:
+                raise RuntimeError(f"{name}: expected 32 elements, got {t.numel()}")
+    out = torch.empty((n, 4, h, w, 8), dtype=torch.float16, device=x.device)
+    d = _lib.CtxBlockH8Desc()
+    d.x, d.N, d.H, d.W, d.Cin, d.C = x.data_ptr(), n, h, w, int(cin), 32
+    d.w1, d.w2, d.w3 = w1.data_ptr(), w2.data_ptr(), w3.data_ptr()
+    d.bias1, d.bias2, d.bias3 = _ptr(bias1), _ptr(bias2), _ptr(bias3)
+    d.bn1_a, d.bn1_b = _ptr(None if bn1 is None else bn1[0]), _ptr(None if bn1 is None else bn1[1])
+    d.bn2_a, d.bn2_b = _ptr(None if bn2 is None else bn2[0]), _ptr(None if bn2 is None else bn2[1])
+    d.slope, d.out = float(slope), out.data_ptr()
+    if ops.TIMING is None:
+        check(lib.slu_ctx_block_h8_fwd(C.byref(d), _stream()), "slu_ctx_block_h8_fwd")
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.slu_ctx_block_h8_fwd(C.byref(d), _stream()), "slu_ctx_block_h8_fwd")
+    e1.record()
+    px = float(n * h * w)
+    flops = 2.0 * (cin * 32 + 2 * 9 * 32 * 32) * px
+    # SURVEY 8(d) layer-granular bytes of the three convs (each reads its input and writes its output once) vs what the fused kernel moves
+    nbytes = px * 2.0 * ((8 * g + 32) + (32 + 32) + (32 + 32)) + 2.0 * (32 * cin + 2 * 9 * 32 * 32)
+    min_bytes = px * 2.0 * (8 * g + 32) + 2.0 * (32 * cin + 2 * 9 * 32 * 32)
+    ops.TIMING.append((f"ctx_h8_kernel<{1 if cin <= 16 else 2}>", flops, nbytes, e0, e1, min_bytes))
+    ops.TIMING_TAGS.append(f"N{n} {cin}->32 k1 + 32->32 k3d1 + 32->32 k3d2 fused {h}x{w}")
+    return out
+
+
 def head_mc_h8(x: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor], classes: int, passes: int, batch: int, eps: float = 1e-12):
     """x: h8 [T*B, G, H, W, 8] (pass-major) -> (p_bar [B,C,H,W], H_norm [B,H,W], MI_norm [B,H,W], preds int64 [B,H,W]): the 1x1 head
     conv and the MC-dropout reduction of trainer.py:1143-1154 in one launch (slu_head_mc_h8)."""

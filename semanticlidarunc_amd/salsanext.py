@@ -42,6 +42,8 @@ _TRAIN_CONV_PRECISION = os.environ.get("SLU_TRAIN_CONV_PRECISION", "fp32")
 _FUSE_TAIL = os.environ.get("SLU_FUSE_TAIL", "1") != "0"
 # the fused kernel also covers 128 channels, but there (MFMA-bound layers, 4-row tiles) it measured slower than the two launches
 _FUSE_TAIL_MAX_C = int(os.environ.get("SLU_FUSE_TAIL_MAX_C", "64"))
+# half-precision inference: a ResContextBlock (1x1 -> 3x3 -> 3x3 dilated + shortcut) as one launch (0: three launches; A/B switch)
+_FUSE_CTX = os.environ.get("SLU_FUSE_CTX", "1") != "0"
 # half-precision MC inference: head conv + softmax / entropy / MI reduction over the T passes as one launch (0: logits + slu_mc_reduce)
 _FUSE_HEAD_MC = os.environ.get("SLU_FUSE_HEAD_MC", "1") != "0"
 
@@ -207,6 +209,21 @@ class ResContextBlock(_FusedBlock):
         self.bn2 = nn.BatchNorm2d(out_filters)
 
     def forward(self, x):
+        if (_FUSE_CTX and x.dtype == torch.float16 and x.dim() == 5 and self.conv1.out_channels == 32
+                and h8.ctx_block_supported(self.conv1.in_channels, 32, x.shape[2], x.shape[3])):
+            # half-precision inference: the whole block as one launch, shortcut and a1 never leave the CU (csrc/ctx_block_h8.hip)
+            packs, folded = [], []
+            for conv, bn in ((self.conv1, None), (self.conv2, self.bn1), (self.conv3, self.bn2)):
+                p = self._prepared(conv)
+                wkey = _tkey(conv.weight)
+                if p.key8 != wkey:
+                    p.wpack8 = h8.pack_conv_weight_h8(conv.weight.detach().contiguous())
+                    p.key8 = wkey
+                packs.append(p.wpack8)
+                fa, fb = self._folded_bn(p, bn)
+                folded.append(None if fa is None else (fa, fb))
+            b = [None if c.bias is None else c.bias.detach() for c in (self.conv1, self.conv2, self.conv3)]
+            return h8.ctx_block_h8(x, self.conv1.in_channels, packs[0], packs[1], packs[2], b[0], b[1], folded[1], b[2], folded[2], _SLOPE)
         shortcut = self._run(self.conv1, None, [ConvSource(x)])
         a1 = self._run(self.conv2, self.bn1, [ConvSource(shortcut)])
         return self._run(self.conv3, self.bn2, [ConvSource(a1)], resid=shortcut)
@@ -374,11 +391,14 @@ class SalsaNext(_FusedBlock):
         n = int(T) * b
         x = x.contiguous().float()
         half = _CONV_PRECISION == "f16"
+        if scales is None and not torch.cuda.is_current_stream_capturing():
+            scales = self._predraw_dropout(n, x.device)
         if half:
             x = h8.to_h8(x)
         d = self.downCntx3(self.downCntx2(self.downCntx(x)))
         d0c, d0b = self.resBlock1(d, scales, "resBlock1")               # no dropout in this block
         full2 = self.resBlock2.features(d0c)                             # deterministic; also the skip of upBlock3
+        self._join_dropout()
         s2 = _draw(self.resBlock2.dropout, n, self.resBlock2.conv5.out_channels, x.device, scales, "resBlock2.dropout")
         # from here on: T*B stacked passes
         d1c = h8.avgpool3s2_h8(full2, s2, n) if half else ops.avgpool3s2_bcast(full2, s2, n)
@@ -397,6 +417,38 @@ class SalsaNext(_FusedBlock):
             return False
         return not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
 
+    # (site, channels) of every Dropout2d applied in forward, in the reference's call order (SalsaNext.py:98,106,145,149,168)
+    _DROPOUT_SITES = (("resBlock2", "dropout", 128), ("resBlock3", "dropout", 256), ("resBlock4", "dropout", 256), ("resBlock5", "dropout", 256),
+                      ("upBlock1", "dropout1", 64), ("upBlock1", "dropout2", 320), ("upBlock1", "dropout3", 128),
+                      ("upBlock2", "dropout1", 32), ("upBlock2", "dropout2", 288), ("upBlock2", "dropout3", 128),
+                      ("upBlock3", "dropout1", 32), ("upBlock3", "dropout2", 160), ("upBlock3", "dropout3", 64))
+
+    def _predraw_dropout(self, n: int, device):
+        """Inference with live Dropout2d (MC sampling): draw the multipliers of all 13 sites up front, through the real nn.Dropout2d
+        children and in the reference's call order (same RNG consumption as drawing them inside the blocks), on a side stream, so the
+        ~60 tiny launches overlap the context blocks instead of sitting between the convs.  None when no site is active."""
+        sites = [(f"{blk}.{name}", getattr(getattr(self, blk), name), c) for blk, name, c in self._DROPOUT_SITES]
+        if not any(d.training and d.p > 0.0 for _, d, _ in sites):
+            return None
+        main = torch.cuda.current_stream(device)
+        side = self.__dict__.get("_drop_stream")
+        if side is None or side.device != device:
+            side = self.__dict__["_drop_stream"] = torch.cuda.Stream(device)
+        out: Dict[str, torch.Tensor] = {}
+        with torch.cuda.stream(side):
+            for key, drop, c in sites:
+                s = _draw(drop, n, c, device, None, key)
+                if s is not None:
+                    s.record_stream(main)
+                    out[key] = s
+        self.__dict__["_drop_event"] = side.record_event()
+        return out
+
+    def _join_dropout(self):
+        ev = self.__dict__.pop("_drop_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def _forward(self, x, scales):
         if not isinstance(x, torch.Tensor) or x.dim() != 4:
             raise RuntimeError("SalsaNext expects a [B, C, H, W] tensor")
@@ -406,12 +458,15 @@ class SalsaNext(_FusedBlock):
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise RuntimeError("SalsaNext needs H and W divisible by 16")
         x = x.contiguous().float()
+        if scales is None and self._inference_only() and not torch.cuda.is_current_stream_capturing():
+            scales = self._predraw_dropout(x.shape[0], x.device)
         if _CONV_PRECISION == "f16" and self._inference_only():
             x = h8.to_h8(x)             # everything downstream stays in the fp16 channel-blocked layout
         d = self.downCntx(x)
         d = self.downCntx2(d)
         d = self.downCntx3(d)
         d0c, d0b = self.resBlock1(d, scales, "resBlock1")
+        self._join_dropout()                      # the first consumer of a multiplier is resBlock2's pooling
         d1c, d1b = self.resBlock2(d0c, scales, "resBlock2")
         d2c, d2b = self.resBlock3(d1c, scales, "resBlock3")
         d3c, d3b = self.resBlock4(d2c, scales, "resBlock4")

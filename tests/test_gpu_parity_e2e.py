@@ -20,11 +20,18 @@ T, NCLS, BAR = 8, 20, 1e-3
 
 
 def _oracle_scan(sd, x1, seed):
+    """(stacked multipliers, oracle MC reduction, labels).  Labels come from the oracle too, but from its deterministic eval pass
+    (argmax + 30 % seeded noise, empty returns -> class 0): labels tied to the MC mean's OWN argmax would make every near-tie pixel
+    "correct" for the oracle path by construction and "wrong" for any other path, which no real label does."""
     g = torch.Generator().manual_seed(seed)
     scales = [osalsa.draw_dropout_scales(1, 0.2, g) for _ in range(T)]
     with torch.no_grad():
         outs = [osalsa.salsanext_forward(sd, x1, s) for s in scales]
-    return {k: torch.cat([s[k] for s in scales], 0) for k in scales[0]}, ounc.mc_reduce(torch.stack(outs, 0))
+        det = osalsa.salsanext_forward(sd, x1).argmax(1)
+    gl = torch.Generator().manual_seed(900 + seed)
+    labels = torch.where(torch.rand(det.shape, generator=gl) < 0.30, torch.randint(1, NCLS, det.shape, generator=gl), det)
+    labels = labels.masked_fill(x1[:, 0] == 0, 0)
+    return {k: torch.cat([s[k] for s in scales], 0) for k in scales[0]}, ounc.mc_reduce(torch.stack(outs, 0)), labels
 
 
 @pytest.mark.parametrize("precision,share_prefix", [("f16", False), ("f16", True), ("fp32", False)])
@@ -42,10 +49,7 @@ def test_miou_ece_entropy_of_the_gpu_path_match_the_oracle_path(cuda, precision,
     try:
         for b in range(4):
             x1 = x[b:b + 1].contiguous()
-            stacked, (p_w, h_w, mi_w, pred_w) = _oracle_scan(sd, x1, seed=b)
-            g = torch.Generator().manual_seed(900 + b)                                    # labels: oracle argmax + 30 % noise, empty -> 0
-            labels = torch.where(torch.rand(pred_w.shape, generator=g) < 0.30, torch.randint(1, NCLS, pred_w.shape, generator=g), pred_w)
-            labels = labels.masked_fill(x1[:, 0] == 0, 0)
+            stacked, (p_w, h_w, mi_w, pred_w), labels = _oracle_scan(sd, x1, seed=b)
             model.eval()
             with torch.no_grad(), dropout_sampling(model, True):
                 xg = x1.to(cuda)
@@ -76,7 +80,7 @@ def test_miou_ece_entropy_of_the_gpu_path_match_the_oracle_path(cuda, precision,
     ece_w, mce_w = ometrics.ece_from_bins(*ometrics.ece_bins_over(o_ece.conf, o_ece.correct, ometrics.ece_edges(o_ece.conf, 15)))
     (ece_ag, _), _ = ece_all.compute()[:2]
     ece_aw, _ = ometrics.ece_from_bins(*ometrics.ece_bins(np.concatenate(confs), np.concatenate(oks), 15))
-    assert 0.3 < miou_w < 0.9 and ece_w > 0.01                                  # a non-trivial operating point
+    assert 0.05 < miou_w < 0.95 and ece_w > 0.01                                # a non-trivial operating point (random labels give 0.0075)
     assert o_ece.seen == ece._seen and o_ece.conf.size == ece._conf.numel()     # 4 x ~118 k valid pixels: under the cap, nothing dropped
     assert abs(miou_g - miou_w) <= BAR, (miou_g, miou_w)
     assert abs(ece_g - ece_w) <= BAR and abs(ece_ag - ece_aw) <= BAR, (ece_g, ece_w, ece_ag, ece_aw)
