@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 16
+#define SLU_ABI_VERSION 17
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -434,6 +434,27 @@ int slu_dirichlet_loss_bwd_ex(const float* alpha, const int64_t* labels, int B, 
 size_t slu_spherical_projection_workspace_bytes(int N, int H, int W);
 int slu_spherical_projection(const double* pc, int N, int C, int H, int W, int use_data_theta_range, double theta_min, double theta_max,
                              void* workspace, size_t workspace_bytes, float* img, double* theta_range_out, slu_stream_t stream);
+/* The same with the remaining options of the reference function and the dataloaders' flip augmentation:
+ *   bins_h: explicit row bins, float64 [H] on the device, strictly monotone (bins_increasing 0 / 1), rows = numpy.digitize(theta, bins_h) - 1
+ *           (dataset/utils.py:326-327,334; NULL: the reversed linspace of the theta range);
+ *   keep_farthest: sort_largest_first=True of the reference -- points are then written in ASCENDING range order, so the farthest
+ *           point of a pixel survives (:301-304);
+ *   flip: write the image with reversed columns and negated y (dataloader_semantic_KITTI.py:72-74). */
+int slu_spherical_projection_ex(const double* pc, int N, int C, int H, int W, int use_data_theta_range, double theta_min, double theta_max,
+                                const double* bins_h, int bins_increasing, int keep_farthest, int flip, void* workspace, size_t workspace_bytes,
+                                float* img, double* theta_range_out, slu_stream_t stream);
+
+/* ---- the two ends of the dataloader's __getitem__ around the projection (dataloader_semantic_KITTI.py:31-99) --------
+ * slu_kitti_decode: xyzi float32 [N][4] (the .bin file), label uint32 [N] (the .label file; low 16 bits = semantic id), lut int32
+ *   [lut_size] = dataset/definitions.py id_map (-1 where the dict has no key) -> pc float64 [N][5] = (x, y, z, intensity, class);
+ *   rotate != 0: xyz @ Rz with the given cosine / sine (rotate_z, dataset/utils.py:4-18).  bad_count int32[1] (zero it first) counts
+ *   labels without a LUT entry (the reference raises KeyError).
+ * slu_range_image_split: projected image float32 [H][W][C >= 5] (x, y, z, intensity, class) and optionally its normals [H][W][3] ->
+ *   range [H][W] = |xyz|, reflectivity [H][W], xyz [3][H][W], normals_chw [3][H][W], labels int64 [H][W] (:83-99). */
+int slu_kitti_decode(const float* xyzi, const uint32_t* label, int N, const int32_t* lut, int lut_size, int rotate, double cos_a, double sin_a,
+                     double* pc, int32_t* bad_count, slu_stream_t stream);
+int slu_range_image_split(const float* img, const float* normals, int H, int W, int C, float* range, float* refl, float* xyz, float* normals_chw,
+                          int64_t* labels, slu_stream_t stream);
 
 /* ---- surface normals of the projected image (dataset/utils.py:30-58 build_normal_xyz; inference_ouster.py:70) ------
  * xyz: fp32 [H][W][channels >= 3] (x, y, z first); normals: fp32 [H][W][3] = -(d xyz/d col x d xyz/d row) / (|.| + 1e-10) with the 3x3

@@ -12,12 +12,16 @@ def deflection(x, y, z):
     return np.arctan2(y, x), -np.arctan2(np.sqrt(x ** 2 + y ** 2), z) + np.pi / 2
 
 
-def spherical_projection(pc, height=64, width=2048, theta_range=None):
+def spherical_projection(pc, height=64, width=2048, theta_range=None, sort_largest_first=False, bins_h=None):
     r = np.sqrt(pc[:, 0] ** 2 + pc[:, 1] ** 2 + pc[:, 2] ** 2)
-    pc = pc[r.argsort()[::-1]]                      # farthest first: the nearest point is written last and survives
+    order = r.argsort()
+    # default: farthest first, so the nearest point is written last and survives; sort_largest_first=True (utils.py:301-304) writes in
+    # ASCENDING range order instead -- the farthest point survives
+    pc = pc[order] if sort_largest_first else pc[order[::-1]]
     phi, theta = deflection(pc[:, 0], pc[:, 1], pc[:, 2])
     theta_min, theta_max = (theta.min(), theta.max()) if theta_range is None else theta_range
-    bins_h = np.linspace(theta_min, theta_max, height)[::-1]
+    if bins_h is None:
+        bins_h = np.linspace(theta_min, theta_max, height)[::-1]
     bins_w = np.linspace(-np.pi, np.pi, width)[::-1]
     idx_h = np.digitize(theta, bins_h) - 1
     idx_w = np.digitize(phi, bins_w) - 1

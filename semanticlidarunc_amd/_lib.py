@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -181,6 +181,10 @@ SIGNATURES = {
     "slu_spherical_projection_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_spherical_projection": (C.c_int, [c_f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_size_t,
                                            c_f32p, c_f64p, c_stream]),
+    "slu_spherical_projection_ex": (C.c_int, [c_f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, c_f64p, C.c_int, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_size_t, c_f32p, c_f64p, c_stream]),
+    "slu_kitti_decode": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, c_f64p, C.c_void_p, c_stream]),
+    "slu_range_image_split": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, c_stream]),
     "slu_lovasz_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_lovasz_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_size_t, c_f32p,
                                  c_f32p, c_f32p, c_stream]),

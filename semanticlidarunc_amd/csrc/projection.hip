@@ -67,37 +67,63 @@ __device__ __forceinline__ double from_orderable(unsigned long long k) {
   return __longlong_as_double((long long)u);
 }
 
-// pass 1: pixel of every point, nearest range per pixel
+// numpy.digitize(v, bins) - 1 for an explicit monotone array (right = False): decreasing bins -> #{bins > v} - 1, increasing bins ->
+// #{bins <= v} - 1 (both counts are prefixes of the array); -1 wraps to the last row like numpy's negative index
+__device__ __forceinline__ int digitize_bins(double v, const double* __restrict__ bins, int n, int increasing) {
+  int a = 0, b = n;                       // the count lies in [a, b]
+  while (a < b) {
+    const int mid = (a + b) >> 1;
+    const bool in_prefix = increasing ? (bins[mid] <= v) : (bins[mid] > v);
+    if (in_prefix) a = mid + 1; else b = mid;
+  }
+  const int idx = a - 1;
+  return idx < 0 ? n - 1 : idx;
+}
+
+// pass 1: pixel of every point, nearest (or, keep_farthest, farthest) range per pixel
 __global__ __launch_bounds__(256) void project_kernel(const double* __restrict__ pc, int N, int C, int H, int W, int use_data_range, double tmin, double tmax,
-                                                      const unsigned long long* __restrict__ mm, int* __restrict__ pixel,
-                                                      unsigned long long* __restrict__ best_r) {
+                                                      const unsigned long long* __restrict__ mm, const double* __restrict__ bins_h, int bins_increasing,
+                                                      int keep_farthest, int* __restrict__ pixel, unsigned long long* __restrict__ best_r) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   if (use_data_range) { tmin = from_orderable(mm[0]); tmax = from_orderable(mm[1]); }
   double phi, theta, r;
   angles(pc + (size_t)i * C, phi, theta, r);
-  const int row = digitize_desc(theta, tmin, tmax, H), col = digitize_desc(phi, -kPi, kPi, W);
+  const int row = bins_h ? digitize_bins(theta, bins_h, H, bins_increasing) : digitize_desc(theta, tmin, tmax, H);
+  const int col = digitize_desc(phi, -kPi, kPi, W);
   const int px = row * W + col;
   pixel[i] = px;
-  atomicMin(&best_r[px], (unsigned long long)__double_as_longlong(r));      // r >= 0: the bit pattern is monotone
+  const unsigned long long rb = (unsigned long long)__double_as_longlong(r);      // r >= 0: the bit pattern is monotone
+  if (keep_farthest) atomicMax(&best_r[px], rb); else atomicMin(&best_r[px], rb);
 }
 
-// pass 2: among the points at the nearest range of their pixel, the smallest index
+// pass 2: among the points at the winning range of their pixel, the smallest index (nearest mode: the reference's descending argsort
+// keeps an unspecified one of them) / the largest index (farthest mode)
 __global__ __launch_bounds__(256) void winner_kernel(const double* __restrict__ pc, int N, int C, const int* __restrict__ pixel,
-                                                     const unsigned long long* __restrict__ best_r, int* __restrict__ winner) {
+                                                     const unsigned long long* __restrict__ best_r, int keep_farthest, int* __restrict__ winner) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   double phi, theta, r;
   angles(pc + (size_t)i * C, phi, theta, r);
-  if ((unsigned long long)__double_as_longlong(r) == best_r[pixel[i]]) atomicMin(&winner[pixel[i]], i);
+  if ((unsigned long long)__double_as_longlong(r) == best_r[pixel[i]]) {
+    if (keep_farthest) atomicMax(&winner[pixel[i]], i); else atomicMin(&winner[pixel[i]], i);
+  }
 }
 
-// pass 3: copy the winner's channels (float32 image, zeros where no point fell)
-__global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ pc, int C, int HW, const int* __restrict__ winner, float* __restrict__ img) {
+// pass 3: copy the winner's channels (float32 image, zeros where no point fell).  flip: the horizontal-flip augmentation of the
+// dataloaders (dataloader_semantic_KITTI.py:72-74: columns reversed, y negated) applied while writing.
+__global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ pc, int C, int H, int W, const int* __restrict__ winner, int none,
+                                                     int flip, float* __restrict__ img) {
   const int px = blockIdx.x * blockDim.x + threadIdx.x;
-  if (px >= HW) return;
+  if (px >= H * W) return;
   const int w = winner[px];
-  for (int c = 0; c < C; ++c) img[(size_t)px * C + c] = w == 0x7fffffff ? 0.0f : (float)pc[(size_t)w * C + c];
+  const int row = px / W, col = px - row * W;
+  float* o = img + ((size_t)row * W + (flip ? W - 1 - col : col)) * C;
+  for (int c = 0; c < C; ++c) {
+    float v = w == none ? 0.0f : (float)pc[(size_t)w * C + c];
+    if (flip && c == 1) v = -v;
+    o[c] = v;
+  }
 }
 
 __global__ void theta_range_kernel(const unsigned long long* __restrict__ mm, int use_data_range, double tmin, double tmax, double* __restrict__ out) {
@@ -123,8 +149,9 @@ extern "C" size_t slu_spherical_projection_workspace_bytes(int N, int H, int W) 
   return carve_proj(nullptr, N, H * W, nullptr, nullptr, nullptr, nullptr);
 }
 
-extern "C" int slu_spherical_projection(const double* pc, int N, int C, int H, int W, int use_data_theta_range, double theta_min, double theta_max,
-                                        void* workspace, size_t workspace_bytes, float* img, double* theta_range_out, slu_stream_t stream) {
+extern "C" int slu_spherical_projection_ex(const double* pc, int N, int C, int H, int W, int use_data_theta_range, double theta_min, double theta_max,
+                                           const double* bins_h, int bins_increasing, int keep_farthest, int flip, void* workspace,
+                                           size_t workspace_bytes, float* img, double* theta_range_out, slu_stream_t stream) {
   if (!pc || !workspace || !img || N <= 0 || C < 3 || H <= 0 || W <= 0 || (long long)H * W > 0x7ffffffe) return SLU_EINVAL;
   unsigned long long *mm, *best;
   int *pixel, *winner;
@@ -132,19 +159,99 @@ extern "C" int slu_spherical_projection(const double* pc, int N, int C, int H, i
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return SLU_EINVAL;
   hipStream_t st = slu_stream(stream);
   const int HW = H * W;
-  // theta min -> all ones, theta max -> 0, nearest range -> all ones (above any finite range), winner -> INT_MAX (= "no point")
+  // theta min -> all ones, theta max -> 0; winning range -> all ones (nearest: above any finite range) / 0 (farthest);
+  // winner -> INT_MAX (nearest) / -1 (farthest) = "no point"
+  const int none = keep_farthest ? -1 : 0x7fffffff;
   if (hipMemsetAsync(mm, 0xff, sizeof(unsigned long long), st) != hipSuccess || hipMemsetAsync(mm + 1, 0, sizeof(unsigned long long), st) != hipSuccess ||
-      hipMemsetAsync(best, 0xff, (size_t)HW * sizeof(unsigned long long), st) != hipSuccess)
+      hipMemsetAsync(best, keep_farthest ? 0x00 : 0xff, (size_t)HW * sizeof(unsigned long long), st) != hipSuccess)
     return SLU_ELAUNCH;
   const unsigned nbp = (unsigned)((N + 255) / 256), nbx = (unsigned)((HW + 255) / 256);
-  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(winner), 0x7fffffff, (size_t)HW, st) != hipSuccess) return SLU_ELAUNCH;
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(winner), none, (size_t)HW, st) != hipSuccess) return SLU_ELAUNCH;
+  const int data_range = use_data_theta_range && !bins_h;
   if (use_data_theta_range)
     hipLaunchKernelGGL(theta_minmax_kernel, dim3(nbp > 256 ? 256 : nbp), dim3(256), 0, st, pc, N, C, mm);
-  hipLaunchKernelGGL(project_kernel, dim3(nbp), dim3(256), 0, st, pc, N, C, H, W, use_data_theta_range, theta_min, theta_max, mm, pixel, best);
-  hipLaunchKernelGGL(winner_kernel, dim3(nbp), dim3(256), 0, st, pc, N, C, pixel, best, winner);
-  hipLaunchKernelGGL(gather_kernel, dim3(nbx), dim3(256), 0, st, pc, C, HW, winner, img);
+  hipLaunchKernelGGL(project_kernel, dim3(nbp), dim3(256), 0, st, pc, N, C, H, W, data_range, theta_min, theta_max, mm, bins_h, bins_increasing,
+                     keep_farthest, pixel, best);
+  hipLaunchKernelGGL(winner_kernel, dim3(nbp), dim3(256), 0, st, pc, N, C, pixel, best, keep_farthest, winner);
+  hipLaunchKernelGGL(gather_kernel, dim3(nbx), dim3(256), 0, st, pc, C, H, W, winner, none, flip, img);
   if (theta_range_out)
     hipLaunchKernelGGL(theta_range_kernel, dim3(1), dim3(1), 0, st, mm, use_data_theta_range, theta_min, theta_max, theta_range_out);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_spherical_projection(const double* pc, int N, int C, int H, int W, int use_data_theta_range, double theta_min, double theta_max,
+                                        void* workspace, size_t workspace_bytes, float* img, double* theta_range_out, slu_stream_t stream) {
+  return slu_spherical_projection_ex(pc, N, C, H, W, use_data_theta_range, theta_min, theta_max, nullptr, 0, 0, 0, workspace, workspace_bytes, img,
+                                     theta_range_out, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The two ends of the dataloader's __getitem__ around the projection (dataloader_semantic_KITTI.py:31-99):
+//   decode   .bin float32 [N][4] (x, y, z, intensity) + .label uint32 [N] -> float64 [N][5] (x, y, z, i, id_map[label & 0xFFFF]),
+//            optional yaw rotation (rotate_z, dataset/utils.py:4-18: points @ R, float64)                                      (:36-56)
+//   split    projected image [H][W][C >= 5] (+ normals [H][W][3]) -> range = |xyz| (float32, (x^2 + y^2) + z^2 as numpy sums it),
+//            reflectivity, xyz and normals channel-first, semantics int64                                                       (:83-99)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void kitti_decode_kernel(const float* __restrict__ xyzi, const unsigned* __restrict__ label, int N,
+                                                           const int* __restrict__ lut, int lut_size, int rotate, double ca, double sa,
+                                                           double* __restrict__ pc, int* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float4 p = reinterpret_cast<const float4*>(xyzi)[i];
+  double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+  if (rotate) {                           // [x y z] @ [[c, -s, 0], [s, c, 0], [0, 0, 1]]: plain products and sums, no fused multiply-add
+    const double xr = __dadd_rn(__dadd_rn(__dmul_rn(x, ca), __dmul_rn(y, sa)), __dmul_rn(z, 0.0));
+    const double yr = __dadd_rn(__dadd_rn(__dmul_rn(x, -sa), __dmul_rn(y, ca)), __dmul_rn(z, 0.0));
+    x = xr;
+    y = yr;
+  }
+  const unsigned sem = label[i] & 0xFFFFu;
+  int cls = sem < (unsigned)lut_size ? lut[sem] : -1;
+  if (cls < 0) {                          // the reference's dict lookup raises KeyError: counted here, raised by the host wrapper
+    atomicAdd(bad, 1);
+    cls = 0;
+  }
+  double* o = pc + (size_t)i * 5;
+  o[0] = x; o[1] = y; o[2] = z; o[3] = (double)p.w; o[4] = (double)cls;
+}
+
+__global__ __launch_bounds__(256) void range_image_split_kernel(const float* __restrict__ img, const float* __restrict__ normals, int HW, int C,
+                                                                float* __restrict__ range, float* __restrict__ refl, float* __restrict__ xyz,
+                                                                float* __restrict__ normals_chw, int64_t* __restrict__ labels) {
+#pragma clang fp contract(off)
+  const int px = blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= HW) return;
+  const float* p = img + (size_t)px * C;
+  const float x = p[0], y = p[1], z = p[2];
+  range[px] = sqrtf((x * x + y * y) + z * z);
+  refl[px] = p[3];
+  xyz[px] = x; xyz[HW + px] = y; xyz[2 * (size_t)HW + px] = z;
+  labels[px] = (int64_t)p[4];
+  if (normals) {
+    normals_chw[px] = normals[(size_t)px * 3];
+    normals_chw[HW + px] = normals[(size_t)px * 3 + 1];
+    normals_chw[2 * (size_t)HW + px] = normals[(size_t)px * 3 + 2];
+  }
+}
+
+}  // namespace
+
+extern "C" int slu_kitti_decode(const float* xyzi, const uint32_t* label, int N, const int32_t* lut, int lut_size, int rotate, double cos_a, double sin_a,
+                                double* pc, int32_t* bad_count, slu_stream_t stream) {
+  if (!xyzi || !label || !lut || !pc || !bad_count || N <= 0 || lut_size <= 0 || ((uintptr_t)xyzi & 15)) return SLU_EINVAL;
+  hipLaunchKernelGGL(kitti_decode_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, slu_stream(stream), xyzi, label, N, lut, lut_size, rotate,
+                     cos_a, sin_a, pc, bad_count);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_range_image_split(const float* img, const float* normals, int H, int W, int C, float* range, float* refl, float* xyz,
+                                     float* normals_chw, int64_t* labels, slu_stream_t stream) {
+  if (!img || !range || !refl || !xyz || !labels || H <= 0 || W <= 0 || C < 5 || (normals && !normals_chw) || (long long)H * W > 0x7ffffffe) return SLU_EINVAL;
+  const int HW = H * W;
+  hipLaunchKernelGGL(range_image_split_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, slu_stream(stream), img, normals, HW, C, range, refl,
+                     xyz, normals_chw, labels);
   SLU_CHECK_LAUNCH();
 }
 

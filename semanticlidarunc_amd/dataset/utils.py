@@ -21,24 +21,33 @@ def to_deflection_coordinates(x, y, z):
 def spherical_projection(pc, height=64, width=2048, theta_range=None, th=1.0, sort_largest_first=False, bins_h=None, max_range=None,
                          device="cuda"):
     """pc: [N, C] array or tensor (x, y, z, ...).  The nearest point of a pixel survives (the reference writes the points in
-    descending range order); `th` / `max_range` are accepted and unused, as in the reference."""
+    descending range order) unless sort_largest_first (ascending order: the farthest survives); bins_h: explicit monotone row bins;
+    `th` / `max_range` are accepted and unused, as in the reference."""
     if torch.utils.data.get_worker_info() is not None:
         # a forked DataLoader worker must not touch the GPU: hand the call to the module this file shadows (the reference's numpy code)
         if _shadowed is not None:
             return _shadowed.spherical_projection(pc, height, width, theta_range, th, sort_largest_first, bins_h, max_range)
         raise RuntimeError("spherical_projection: the HIP projection cannot run inside a DataLoader worker process; "
                            "project in the main process (num_workers=0) or keep the reference's dataset/utils.py on sys.path")
-    if sort_largest_first or bins_h is not None:
-        raise NotImplementedError("the HIP projection implements the default nearest-point order and linspace row bins")
     t = pc if isinstance(pc, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pc))
     if not t.is_cuda:
         t = t.to(device)
-    img, tr = ops.spherical_projection(t.to(torch.float64).contiguous(), height, width, theta_range)
+    bins_dev, increasing = None, False
+    if bins_h is not None:
+        bins_np = np.ascontiguousarray(np.asarray(bins_h, dtype=np.float64)).reshape(-1)
+        d = np.diff(bins_np)
+        if bins_np.size != int(height) or not (np.all(d > 0) or np.all(d < 0)):
+            raise ValueError("bins_h must hold `height` strictly monotone row bins")      # numpy.digitize rejects non-monotone bins too
+        increasing = bool(d[0] > 0) if d.size else False
+        bins_dev = torch.from_numpy(bins_np).to(t.device)
+    img, tr = ops.spherical_projection(t.to(torch.float64).contiguous(), height, width, theta_range, bins_h=bins_dev, bins_increasing=increasing,
+                                       keep_farthest=bool(sort_largest_first))
     theta_min, theta_max = (float(v) for v in tr.cpu())
     if theta_range is not None:
         theta_min, theta_max = theta_range
     phi_min, phi_max = -np.pi, np.pi
-    bins_h = np.linspace(theta_min, theta_max, height)[::-1]
+    if bins_h is None:
+        bins_h = np.linspace(theta_min, theta_max, height)[::-1]
     bins_w = np.linspace(phi_min, phi_max, width)[::-1]
     alpha = np.sqrt(np.square(np.stack(width * [bins_h], axis=-1)) + np.square(np.stack(height * [bins_w], axis=0)))
     return img.cpu().numpy(), alpha, (theta_min, theta_max), (phi_min, phi_max)

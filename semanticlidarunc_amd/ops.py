@@ -909,18 +909,74 @@ def dirichlet_loss_bwd_ex(alpha: torch.Tensor, labels: torch.Tensor, kind: str, 
 # ------------------------------------------------------------------------------------------------
 # spherical projection (dataset/utils.py of the reference)
 # ------------------------------------------------------------------------------------------------
-def spherical_projection(pc: torch.Tensor, height: int, width: int, theta_range=None):
-    """pc float64 [N, C >= 3] on the GPU -> (img fp32 [H, W, C], theta_range float64 [2] on the device); nearest point per pixel."""
+def spherical_projection(pc: torch.Tensor, height: int, width: int, theta_range=None, bins_h: Optional[torch.Tensor] = None,
+                         bins_increasing: bool = False, keep_farthest: bool = False, flip: bool = False, out: Optional[torch.Tensor] = None):
+    """pc float64 [N, C >= 3] on the GPU -> (img fp32 [H, W, C], theta_range float64 [2] on the device).  Default: the nearest point of a
+    pixel survives; keep_farthest = the reference's sort_largest_first=True; bins_h: float64 [H] explicit monotone row bins on the device;
+    flip: columns reversed and y negated while writing (the dataloaders' flip augmentation)."""
     _req(pc, "pc", torch.float64)
     if pc.dim() != 2 or pc.shape[1] < 3 or pc.shape[0] == 0:
         raise RuntimeError(f"pc: expected [N, C >= 3], got {tuple(pc.shape)}")
     n, c = pc.shape
     lib = _lib.load()
+    if bins_h is not None:
+        _req(bins_h, "bins_h", torch.float64)
+        if bins_h.dim() != 1 or bins_h.numel() != int(height):
+            raise RuntimeError(f"bins_h: expected {int(height)} row bins, got {tuple(bins_h.shape)}")
     ws = torch.empty(lib.slu_spherical_projection_workspace_bytes(n, int(height), int(width)), dtype=torch.uint8, device=pc.device)
-    img = torch.empty((int(height), int(width), c), dtype=torch.float32, device=pc.device)
+    if out is None:
+        img = torch.empty((int(height), int(width), c), dtype=torch.float32, device=pc.device)
+    else:
+        img = _req(out, "out")
+        if tuple(img.shape) != (int(height), int(width), c):
+            raise RuntimeError(f"out: expected {(int(height), int(width), c)}, got {tuple(img.shape)}")
     tr = torch.empty(2, dtype=torch.float64, device=pc.device)
     use_data = theta_range is None
     tmin, tmax = (0.0, 0.0) if use_data else (float(theta_range[0]), float(theta_range[1]))
-    check(lib.slu_spherical_projection(pc.data_ptr(), n, c, int(height), int(width), 1 if use_data else 0, tmin, tmax, ws.data_ptr(), ws.numel(),
-                                       img.data_ptr(), tr.data_ptr(), _stream()), "slu_spherical_projection")
+    check(lib.slu_spherical_projection_ex(pc.data_ptr(), n, c, int(height), int(width), 1 if use_data else 0, tmin, tmax, _ptr(bins_h),
+                                          1 if bins_increasing else 0, 1 if keep_farthest else 0, 1 if flip else 0, ws.data_ptr(), ws.numel(),
+                                          img.data_ptr(), tr.data_ptr(), _stream()), "slu_spherical_projection_ex")
     return img, tr
+
+
+def kitti_decode(xyzi: torch.Tensor, label: torch.Tensor, lut: torch.Tensor, bad_count: torch.Tensor, rotate_deg: Optional[float] = None):
+    """.bin contents fp32 [N, 4] + .label contents int32 [N] (the uint32 words) + id_map LUT int32 -> float64 [N, 5] (x, y, z, i, class);
+    rotate_deg: yaw of dataset.utils.rotate_z.  bad_count int32 [1] accumulates labels without a LUT entry."""
+    import math
+    _req(xyzi, "xyzi")
+    _req(label, "label", torch.int32)
+    _req(lut, "lut", torch.int32)
+    _req(bad_count, "bad_count", torch.int32)
+    if xyzi.dim() != 2 or xyzi.shape[1] != 4 or label.dim() != 1 or label.numel() != xyzi.shape[0] or xyzi.shape[0] == 0:
+        raise RuntimeError(f"kitti_decode: xyzi [N, 4] / label [N] expected, got {tuple(xyzi.shape)} / {tuple(label.shape)}")
+    n = xyzi.shape[0]
+    pc = torch.empty((n, 5), dtype=torch.float64, device=xyzi.device)
+    ang = 0.0 if rotate_deg is None else math.radians(float(rotate_deg))
+    if rotate_deg is not None:
+        import numpy as np                      # the reference builds the matrix with numpy's cos / sin of np.radians(angle)
+        ang = float(np.radians(float(rotate_deg)))
+        ca, sa = float(np.cos(ang)), float(np.sin(ang))
+    else:
+        ca, sa = 1.0, 0.0
+    check(_lib.load().slu_kitti_decode(xyzi.data_ptr(), label.data_ptr(), n, lut.data_ptr(), lut.numel(), 0 if rotate_deg is None else 1, ca, sa,
+                                       pc.data_ptr(), bad_count.data_ptr(), _stream()), "slu_kitti_decode")
+    return pc
+
+
+def range_image_split(img: torch.Tensor, normals: Optional[torch.Tensor], range_out, refl_out, xyz_out, normals_out, labels_out) -> None:
+    """Projected image fp32 [H, W, C >= 5] (+ normals [H, W, 3]) -> the dataloader's outputs written into the given (slices of batch)
+    tensors: range [1,H,W], reflectivity [1,H,W], xyz [3,H,W], normals [3,H,W], labels int64 [1,H,W]."""
+    _req(img, "img")
+    h, w, c = img.shape
+    for t, nme, shape, dt in ((range_out, "range_out", (1, h, w), torch.float32), (refl_out, "refl_out", (1, h, w), torch.float32),
+                              (xyz_out, "xyz_out", (3, h, w), torch.float32), (labels_out, "labels_out", (1, h, w), torch.int64)):
+        _req(t, nme, dt)
+        if tuple(t.shape) != shape:
+            raise RuntimeError(f"{nme}: expected {shape}, got {tuple(t.shape)}")
+    if normals is not None:
+        _req(normals, "normals")
+        _req(normals_out, "normals_out")
+        if tuple(normals.shape) != (h, w, 3) or tuple(normals_out.shape) != (3, h, w):
+            raise RuntimeError("normals: expected [H, W, 3] in and [3, H, W] out")
+    check(_lib.load().slu_range_image_split(img.data_ptr(), _ptr(normals), h, w, c, range_out.data_ptr(), refl_out.data_ptr(), xyz_out.data_ptr(),
+                                            _ptr(normals_out) if normals is not None else None, labels_out.data_ptr(), _stream()), "slu_range_image_split")

@@ -22,8 +22,10 @@ def test_against_reference_golden(cuda):
         diff = np.any(img != g["img:" + tag], axis=-1)
         assert diff.mean() <= 1e-3, (tag, float(diff.mean()))
         assert alpha.shape == (32, 256) and ph == (-np.pi, np.pi)
-    with pytest.raises(NotImplementedError):
-        spherical_projection(g["cloud"], 32, 256, sort_largest_first=True)
+    far, _, _, _ = spherical_projection(g["cloud"], 32, 256, sort_largest_first=True)      # ascending write order: the FARTHEST point survives
+    near = g["img:data_range"]
+    rf, rn = np.linalg.norm(far[..., :3], axis=-1), np.linalg.norm(near[..., :3], axis=-1)
+    assert np.all(rf >= rn - 1e-4) and (rf > rn + 1e-3).mean() > 0.05 and np.array_equal(rf > 0, rn > 0)
     with pytest.raises(RuntimeError):
         ops.spherical_projection(torch.zeros(10, 2, dtype=torch.float64, device=cuda), 4, 8)
 

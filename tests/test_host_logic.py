@@ -99,3 +99,27 @@ def test_ece_compute_from_injected_bins_and_empty_case():
         assert np.isnan(e) and stats.empty
     with pytest.raises(AssertionError):
         ECEAggregator(binning="quantile")
+
+
+def test_id_map_table_and_raw_scan_loader_plumbing(tmp_path):
+    """dataset/definitions.py id_map equals the reference's table (stored in the golden that the reference generated); the worker side of
+    the device input pipeline only reads files and keeps ragged scans as lists through a DataLoader with workers."""
+    from conftest import golden
+    from semanticlidarunc_amd.dataset import gpu_pipeline
+    from semanticlidarunc_amd.dataset.definitions import id_map
+    g = golden("kitti_sample_16000_32x256")
+    assert id_map == {int(k): int(v) for k, v in zip(g["id_map_keys"], g["id_map_values"])}
+    lut = gpu_pipeline.id_map_lut(id_map)
+    assert lut.dtype == torch.int32 and int(lut[259]) == 5 and int(lut[2]) == -1 and lut.numel() == 260
+    paths = []
+    for k, n in enumerate((300, 170, 220)):
+        fb, fl = tmp_path / f"{k:06d}.bin", tmp_path / f"{k:06d}.label"
+        g["xyzi"][:n].tofile(fb)
+        g["label"][:n].tofile(fl)
+        paths.append((str(fb), str(fl)))
+    ds = gpu_pipeline.RawScanDataset(paths)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=2, collate_fn=gpu_pipeline.raw_collate)
+    batches = list(loader)
+    assert [len(b[0]) for b in batches] == [2, 1] and [t.shape[0] for t in batches[0][0]] == [300, 170]
+    assert batches[0][1][1].dtype == torch.int32 and np.array_equal(batches[1][0][0].numpy(), g["xyzi"][:220])
+    assert np.array_equal(batches[0][1][0].numpy().view(np.uint32), g["label"][:300])

@@ -315,3 +315,22 @@ def test_ece_reservoir_and_adaptive_binning_match_reference():
             assert abs(e - float(g["ece:" + tag])) <= 1e-7 and abs(m - float(g["mce:" + tag])) <= 1e-7
     c, _ = ometrics.top_label(g["onehot_probs"], g["onehot_labels"], 0, "probs")
     assert np.array_equal(ometrics.ece_edges(c, 15, "adaptive"), np.linspace(0, 1, 16, dtype=np.float32))   # duplicate quantiles -> uniform
+
+
+def test_kitti_sample_and_projection_options_match_reference():
+    """f-3 (golden: tools/gen_golden_r02.py kitti, produced by the reference's SemanticKitti.__getitem__ / spherical_projection):
+    decode + id_map + rotate + projection + flip + range, and the sort_largest_first / bins_h options of the projection."""
+    from oracle import kitti as okitti, projection as oproj
+    g = golden("kitti_sample_16000_32x256")
+    id_map = {int(k): int(v) for k, v in zip(g["id_map_keys"], g["id_map_values"])}
+    for tag, flip in (("plain", False), ("rot", False), ("flip", True), ("rotflip", True)):
+        angle = None if np.isnan(float(g[f"{tag}:angle"])) else float(g[f"{tag}:angle"])
+        got = okitti.sample(g["xyzi"].tobytes(), g["label"].tobytes(), id_map, (32, 256), angle, flip)
+        for name, arr in zip(("range", "reflectivity", "xyz", "normals", "semantics"), got):
+            assert np.array_equal(arr, g[f"{tag}:{name}"]), (tag, name)
+    cloud = okitti.decode(g["xyzi"].tobytes(), g["label"].tobytes(), id_map)
+    beams = g["beams"]
+    for tag, kw in (("farthest", dict(sort_largest_first=True)), ("bins_h", dict(bins_h=beams)), ("bins_h_increasing", dict(bins_h=beams[::-1].copy())),
+                    ("farthest_bins_h_range", dict(sort_largest_first=True, bins_h=beams, theta_range=(-0.45, 0.05)))):
+        img, _, th, _ = oproj.spherical_projection(cloud, 32, 256, **kw)
+        assert np.array_equal(img, g[f"proj:{tag}:img"]) and np.allclose(th, g[f"proj:{tag}:theta"], rtol=0, atol=0)

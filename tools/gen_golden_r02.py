@@ -88,7 +88,74 @@ def gen_ece():
     print("  oracle.metrics.ECESamples / ece_edges == reference ECEAggregator (buffers, edges, bins identical)")
 
 
-GENERATORS = {"ece": gen_ece}
+def synthetic_kitti_scan(n_points=16000, seed=5):
+    """A LiDAR-like cloud as the two files of a SemanticKITTI frame would hold it: .bin float32 [N,4], .label uint32 [N]
+    (low 16 bits: raw semantic ids of dataset/definitions.py id_map, high 16 bits: an instance id)."""
+    from dataset.definitions import id_map
+    g = np.random.default_rng(seed)
+    az = g.uniform(-np.pi, np.pi, n_points)
+    el = np.radians(g.uniform(-24.8, 2.0, n_points))
+    rng = g.uniform(1.5, 80.0, n_points)
+    xyz = np.stack([rng * np.cos(el) * np.cos(az), rng * np.cos(el) * np.sin(az), rng * np.sin(el)], -1)
+    xyzi = np.concatenate([xyz, g.uniform(0, 1, (n_points, 1))], -1).astype(np.float32)
+    keys = np.array(sorted(id_map), dtype=np.uint32)
+    label = keys[g.integers(0, len(keys), n_points)] | (g.integers(0, 500, n_points).astype(np.uint32) << 16)
+    return xyzi, label.astype(np.uint32)
+
+
+def gen_kitti():
+    """f-3: SemanticKitti.__getitem__ (dataloader_semantic_KITTI.py:31-99) incl. rotate / flip, and spherical_projection with
+    sort_largest_first / bins_h (dataset/utils.py:288-349).  torchvision.transforms and cv2 are absent: the dataloader only CONSTRUCTS a
+    transforms.Compose it never applies, and cv2 is needed for cv2.Scharr inside build_normal_xyz -- served here by oracle.normals'
+    restatement of OpenCV's definition, so the NORMALS of this fixture are not reference-pinned (everything else is)."""
+    import tempfile
+    from oracle import kitti as okitti, normals as onormals, projection as oproj
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.transforms.Compose = lambda ts: ts
+    tv.transforms.ToTensor = lambda: None
+    sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tv.transforms
+    cv2 = sys.modules["cv2"]
+    cv2.CV_32FC1 = 5
+    cv2.Scharr = lambda img, ddepth, dx, dy, scale=1.0: onormals.scharr(img, dx, dy, scale)
+    from dataset.dataloader_semantic_KITTI import SemanticKitti as RefKitti        # reference
+    from dataset.definitions import id_map
+    from dataset.utils import spherical_projection as ref_projection
+    xyzi, label = synthetic_kitti_scan()
+    out = {"xyzi": xyzi, "label": label, "id_map_keys": np.array(sorted(id_map)), "id_map_values": np.array([id_map[k] for k in sorted(id_map)])}
+    with tempfile.TemporaryDirectory() as td:
+        fb, fl = os.path.join(td, "000000.bin"), os.path.join(td, "000000.label")
+        xyzi.tofile(fb)
+        label.tofile(fl)
+        for tag, rotate, flip, seed in (("plain", False, False, 0), ("rot", True, False, 3), ("flip", False, True, 1), ("rotflip", True, True, 2)):
+            # the reference draws np.random.randint(-180, 180) (rotate) and np.random.rand() < 0.5 (flip) from the global numpy RNG
+            np.random.seed(seed)
+            angle = float(np.random.randint(-180, 180)) if rotate else None
+            do_flip = bool(flip and np.random.rand() < 0.5)
+            assert do_flip == flip, "pick a seed whose flip draw fires"
+            np.random.seed(seed)
+            ds = RefKitti([(fb, fl)], rotate=rotate, flip=flip, projection=(32, 256), resize=False)
+            ref = [t.numpy() for t in ds[0]]
+            mine = okitti.sample(xyzi.tobytes(), label.tobytes(), id_map, (32, 256), angle, do_flip)
+            for name, a, b in zip(("range", "reflectivity", "xyz", "normals", "semantics"), ref, mine):
+                assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b), (tag, name)
+                out[f"{tag}:{name}"] = a
+            out[f"{tag}:angle"] = np.float64(angle if angle is not None else np.nan)
+        print("  oracle.kitti.sample == reference SemanticKitti.__getitem__ (range, reflectivity, xyz, semantics bit-identical; normals via the restated Scharr)")
+    cloud = okitti.decode(xyzi.tobytes(), label.tobytes(), id_map)
+    beams = np.radians(np.linspace(2.0, -24.8, 32)) + 1e-3                        # an explicit, decreasing beam-elevation table
+    for tag, kw in (("farthest", dict(sort_largest_first=True)), ("bins_h", dict(bins_h=beams)), ("bins_h_increasing", dict(bins_h=beams[::-1].copy())),
+                    ("farthest_bins_h_range", dict(sort_largest_first=True, bins_h=beams, theta_range=(-0.45, 0.05)))):
+        img_r, alpha_r, th_r, _ = ref_projection(cloud, 32, 256, **kw)
+        img_o, alpha_o, th_o, _ = oproj.spherical_projection(cloud, 32, 256, **kw)
+        assert np.array_equal(img_r, img_o) and np.array_equal(alpha_r, alpha_o) and tuple(th_r) == tuple(th_o), tag
+        out[f"proj:{tag}:img"], out[f"proj:{tag}:theta"] = img_r, np.array(th_r)
+    out["beams"] = beams
+    print("  oracle.projection.spherical_projection(sort_largest_first / bins_h) == reference (bit-identical)")
+    save("kitti_sample_16000_32x256", **out)
+
+
+GENERATORS = {"ece": gen_ece, "kitti": gen_kitti}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(GENERATORS)):
