@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 17
+#define SLU_ABI_VERSION 18
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -244,6 +244,18 @@ int slu_depth_to_space(const float* x, float* y, int N, int Cout, int H, int W, 
                        slu_stream_t stream);
 /* out = value * softmax(score, dim=-1): score [N,1,H,W], value/out [N,C,H,W]; W <= 4096 (AttentionModule :32-38) */
 int slu_row_softmax_mul(const float* score, const float* value, float* out, int N, int C, int H, int W, slu_stream_t stream);
+
+/* ---- pieces of the `semanticFCN_opt` variant (baselines/Reichert/semanticFCN_opt.py) -----------------------------
+ * slu_bilinear_upsample: F.interpolate(x, scale_factor = scale, mode = 'bilinear', align_corners = False) (UpsampleBlock :24-27):
+ *   x [N,C,H,W] -> y [N,C,H*scale,W*scale].
+ * slu_groupnorm_fwd: nn.GroupNorm(groups, C, eps) [+ ReLU] (:20,66-70): statistics per (sample, group) over (C/groups)*HW (biased
+ *   variance, accumulated in fp64), y = (x - mean) * rstd * gamma[c] + beta[c]; mean / rstd fp32 [N*groups] are outputs; y may be x.
+ * slu_spatial_softmax_gate: SpatialAttention's gate (:80-85): w = softmax(score[n] over H*W); out = x * w + x.  x, out [N,C,HW];
+ *   score [N,1,HW]; stats fp32 [2 N] scratch (max, 1 / sum). */
+int slu_bilinear_upsample(const float* x, float* y, int N, int C, int H, int W, int scale, slu_stream_t stream);
+int slu_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int N, int C, int HW, int groups, float eps, int relu, float* mean,
+                      float* rstd, float* y, slu_stream_t stream);
+int slu_spatial_softmax_gate(const float* x, const float* score, float* stats, float* out, int N, int C, int HW, slu_stream_t stream);
 
 /* ---- fp16 channel-blocked ("h8") inference path: BASELINE.json configs[2],[4] (half-precision storage, fp32 accumulate) -------
  * Activation layout: x[N][G = ceil(C/8)][H][W][8] fp16, pad channels = 0, base pointers 16-byte aligned.

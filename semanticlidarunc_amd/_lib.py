@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -167,6 +167,9 @@ SIGNATURES = {
                                          c_stream]),
     "slu_ctx_block_h8_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "slu_ctx_block_h8_fwd": (C.c_int, [C.POINTER(CtxBlockH8Desc), c_stream]),
+    "slu_bilinear_upsample": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_groupnorm_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, c_f32p, c_f32p, c_f32p, c_stream]),
+    "slu_spatial_softmax_gate": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_conv_tail_h8_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "slu_conv_tail_h8_fwd": (C.c_int, [C.POINTER(ConvTailH8Desc), c_stream]),
     "slu_head_mc_h8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_f32p, C.c_int, C.c_float, c_f32p, c_f32p, c_f32p,

@@ -177,3 +177,148 @@ extern "C" int slu_row_softmax_mul(const float* score, const float* value, float
   hipLaunchKernelGGL(row_softmax_mul_kernel, dim3((unsigned)(N * H)), dim3(256), 0, slu_stream(stream), score, value, out, C, H, W);
   SLU_CHECK_LAUNCH();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pieces of the `semanticFCN_opt` variant (baselines/Reichert/semanticFCN_opt.py):
+//   bilinear_up_kernel        F.interpolate(scale_factor = s, mode = 'bilinear', align_corners = False)       UpsampleBlock :24-27
+//   groupnorm_stats_kernel    per (sample, group) mean and 1 / sqrt(var + eps) over (C / G) * H * W           nn.GroupNorm :20,66-70
+//   groupnorm_apply_kernel    y = (x - mean) * rstd * gamma[c] + beta[c]  [-> ReLU]
+//   spatial_softmax_stats / spatial_gate    w = softmax(score over H * W);  out = x * w + x                    SpatialAttention :80-85
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// source index of ATen's area_pixel_compute_source_index (align_corners = False, not cubic): max(0, (dst + 0.5) / s - 0.5)
+__device__ __forceinline__ void bilinear_taps(int dst, int s, int n_in, int& i0, int& i1, float& l0, float& l1) {
+  float src = ((float)dst + 0.5f) * (1.0f / (float)s) - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  i0 = (int)src;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(256) void bilinear_up_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int H, int W, int s) {
+#pragma clang fp contract(off)
+  const int OW = W * s, OH = H * s;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(e % OW);
+    size_t r = e / OW;
+    const int oy = (int)(r % OH);
+    const size_t nc = r / OH;
+    int y0, y1, x0, x1;
+    float hl0, hl1, wl0, wl1;
+    bilinear_taps(oy, s, H, y0, y1, hl0, hl1);
+    bilinear_taps(ox, s, W, x0, x1, wl0, wl1);
+    const float* p = x + nc * (size_t)H * W;
+    y[e] = hl0 * (wl0 * p[(size_t)y0 * W + x0] + wl1 * p[(size_t)y0 * W + x1]) + hl1 * (wl0 * p[(size_t)y1 * W + x0] + wl1 * p[(size_t)y1 * W + x1]);
+  }
+}
+
+// one workgroup per (sample, group): the group's (C / G) * HW values are contiguous in NCHW
+__global__ __launch_bounds__(1024) void groupnorm_stats_kernel(const float* __restrict__ x, size_t per_group, float eps, float* __restrict__ mean,
+                                                               float* __restrict__ rstd) {
+  __shared__ double s_a[16], s_b[16];
+  const float* p = x + (size_t)blockIdx.x * per_group;
+  double a = 0.0, b = 0.0;
+  for (size_t i = threadIdx.x; i < per_group; i += blockDim.x) {
+    const double v = (double)p[i];
+    a += v;
+    b += v * v;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ta += s_a[w]; tb += s_b[w]; }
+    const double m = ta / (double)per_group;
+    double var = tb / (double)per_group - m * m;            // biased variance, as nn.GroupNorm
+    var = var < 0.0 ? 0.0 : var;
+    mean[blockIdx.x] = (float)m;
+    rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                                              size_t total, int C, int cpg, size_t HW, int relu) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t nc = e / HW;
+    const int c = (int)(nc % C);
+    const size_t ng = (nc / C) * (size_t)(C / cpg) + c / cpg;
+    float v = (x[e] - mean[ng]) * rstd[ng] * (gamma ? gamma[c] : 1.0f) + (beta ? beta[c] : 0.0f);
+    y[e] = relu ? fmaxf(v, 0.0f) : v;
+  }
+}
+
+// per sample: max and 1 / sum(exp(s - max)) of the score map [HW]
+__global__ __launch_bounds__(1024) void spatial_softmax_stats_kernel(const float* __restrict__ score, size_t HW, float* __restrict__ stats) {
+  __shared__ float s_r[16];
+  const float* p = score + (size_t)blockIdx.x * HW;
+  float m = -INFINITY;
+  for (size_t i = threadIdx.x; i < HW; i += blockDim.x) m = fmaxf(m, p[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = s_r[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, s_r[w]);
+  __syncthreads();
+  float sum = 0.0f;
+  for (size_t i = threadIdx.x; i < HW; i += blockDim.x) sum += expf(p[i] - m);
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_r[w];
+    stats[2 * blockIdx.x] = m;
+    stats[2 * blockIdx.x + 1] = 1.0f / t;
+  }
+}
+
+__global__ __launch_bounds__(256) void spatial_gate_kernel(const float* __restrict__ x, const float* __restrict__ score, const float* __restrict__ stats,
+                                                           float* __restrict__ out, size_t total, int C, size_t HW) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t hw = e % HW, n = e / HW / C;
+    const float w = expf(score[n * HW + hw] - stats[2 * n]) * stats[2 * n + 1];
+    const float v = x[e];
+    out[e] = v * w + v;
+  }
+}
+
+inline unsigned grid1d(size_t total) {
+  const size_t nb = (total + 255) / 256;
+  return (unsigned)(nb > 65535 ? 65535 : (nb ? nb : 1));
+}
+
+}  // namespace
+
+extern "C" int slu_bilinear_upsample(const float* x, float* y, int N, int C, int H, int W, int scale, slu_stream_t stream) {
+  if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || scale < 1) return SLU_EINVAL;
+  const size_t total = (size_t)N * C * H * W * scale * scale;
+  hipLaunchKernelGGL(bilinear_up_kernel, dim3(grid1d(total)), dim3(256), 0, slu_stream(stream), x, y, total, H, W, scale);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_groupnorm_fwd(const float* x, const float* gamma, const float* beta, int N, int C, int HW, int groups, float eps, int relu,
+                                 float* mean, float* rstd, float* y, slu_stream_t stream) {
+  if (!x || !y || !mean || !rstd || N <= 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups || !(eps >= 0.0f)) return SLU_EINVAL;
+  if ((long long)N * groups > 0x7fffffffLL) return SLU_EUNSUPPORTED;
+  const int cpg = C / groups;
+  hipStream_t st = slu_stream(stream);
+  hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((unsigned)(N * groups)), dim3(1024), 0, st, x, (size_t)cpg * HW, eps, mean, rstd);
+  const size_t total = (size_t)N * C * HW;
+  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(grid1d(total)), dim3(256), 0, st, x, mean, rstd, gamma, beta, y, total, C, cpg, (size_t)HW, relu);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_spatial_softmax_gate(const float* x, const float* score, float* stats, float* out, int N, int C, int HW, slu_stream_t stream) {
+  if (!x || !score || !stats || !out || N <= 0 || C <= 0 || HW <= 0) return SLU_EINVAL;
+  hipStream_t st = slu_stream(stream);
+  hipLaunchKernelGGL(spatial_softmax_stats_kernel, dim3((unsigned)N), dim3(1024), 0, st, score, (size_t)HW, stats);
+  const size_t total = (size_t)N * C * HW;
+  hipLaunchKernelGGL(spatial_gate_kernel, dim3(grid1d(total)), dim3(256), 0, st, x, score, stats, out, total, C, (size_t)HW);
+  SLU_CHECK_LAUNCH();
+}

@@ -116,13 +116,7 @@ class SemanticNetworkWithFPN(nn.Module):
             raise NotImplementedError("only interpolation_mode='nearest' (the reference default) runs on the HIP path")
         self.backbone_name, self.interpolation_mode = backbone, interpolation_mode
         self.num_classes, self.attention, self.multi_scale_meta = num_classes, attention, multi_scale_meta
-        self.meta_channel_dim = meta_channel_dim
-        self.backbone = ResNetContainer(_RESNETS[backbone])
-        bc = [512, 256, 128, 64, 32]
-        self.backbone.conv1 = nn.Conv2d(input_channels + meta_channel_dim, 64, 3, 1, 1, bias=False)
-        self.stem = nn.Sequential(self.backbone.conv1, self.backbone.relu, self.backbone.maxpool)
-        self.layer1, self.layer2 = self.backbone.layer1, self.backbone.layer2
-        self.layer3, self.layer4 = self.backbone.layer3, self.backbone.layer4
+        bc = self._build_encoder(backbone, input_channels, meta_channel_dim)
         self.attention4, self.attention3 = AttentionModule(bc[1], bc[1]), AttentionModule(bc[2], bc[2])
         self.attention2, self.attention1 = AttentionModule(bc[3], bc[3]), AttentionModule(bc[4], bc[4])
         self.fpn_block4, self.fpn_block3 = self._fpn(bc[0], bc[1]), self._fpn(bc[1], bc[2])
@@ -135,6 +129,41 @@ class SemanticNetworkWithFPN(nn.Module):
             nn.Conv2d(up + bc[4], bc[4], 3, 1, 1), nn.BatchNorm2d(bc[4]), nn.ReLU(inplace=True),
             nn.Conv2d(bc[4], bc[4], 3, 1, 1), nn.BatchNorm2d(bc[4]), nn.ReLU(inplace=True),
             nn.ConvTranspose2d(bc[4], num_classes, 4, 2, 1), nn.ELU(inplace=True))
+
+    def _build_encoder(self, backbone, input_channels, meta_channel_dim):
+        """The torchvision-shaped ResNet with the reference's surgery (semanticFCN.py:146-153): conv1 replaced by a 3x3 / stride-1 conv
+        over input + meta channels, `stem` = conv1 -> relu -> maxpool (bn1 skipped), layerN aliases.  Returns the channel ladder."""
+        self.meta_channel_dim = meta_channel_dim
+        self.backbone = ResNetContainer(_RESNETS[backbone])
+        self.backbone.conv1 = nn.Conv2d(input_channels + meta_channel_dim, 64, 3, 1, 1, bias=False)
+        self.stem = nn.Sequential(self.backbone.conv1, self.backbone.relu, self.backbone.maxpool)
+        self.layer1, self.layer2 = self.backbone.layer1, self.backbone.layer2
+        self.layer3, self.layer4 = self.backbone.layer3, self.backbone.layer4
+        return [512, 256, 128, 64, 32]
+
+    def _check_inputs(self, x, meta_channel):
+        if not (isinstance(x, torch.Tensor) and isinstance(meta_channel, torch.Tensor)) or x.dim() != 4 or meta_channel.dim() != 4:
+            raise RuntimeError("SemanticNetworkWithFPN expects x[B,c,H,W] and meta_channel[B,m,H,W]")
+        if not x.is_cuda:
+            raise RuntimeError(f"semanticlidarunc_amd FPN runs on MI355X only: input is on '{x.device}' and there is no CPU fallback")
+        if x.shape[2] % 16 or x.shape[3] % 16:
+            raise RuntimeError("SemanticNetworkWithFPN needs H and W divisible by 16")
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("training of the FPN model is not on the HIP path yet; call .eval() (autograd is not recorded)")
+        return x.contiguous().float(), meta_channel.contiguous().float()
+
+    def _encode(self, x, meta):
+        """(x1, x2, x3, x4): stem + the four ResNet stages with the multi-scale meta injection (semanticFCN.py:279-314)."""
+        m1 = m2 = m3 = None
+        if self.multi_scale_meta:
+            m1, m2, m3 = ops.nearest_down(meta, 2), ops.nearest_down(meta, 4), ops.nearest_down(meta, 8)
+        xs = self._conv("stem", self.backbone.conv1, None, [ConvSource(x), ConvSource(meta)])       # bn1 is skipped by the reference stem
+        xs = ops.maxpool3s2(xs)
+        x1 = self._stage("layer1", self.layer1, xs, None)
+        x2 = self._stage("layer2", self.layer2, x1, m1)
+        x3 = self._stage("layer3", self.layer3, x2, m2)
+        x4 = self._stage("layer4", self.layer4, x3, m3)
+        return x1, x2, x3, x4
 
     @staticmethod
     def _fpn(cin, cout):
@@ -252,25 +281,8 @@ class SemanticNetworkWithFPN(nn.Module):
         return ops.row_softmax_mul(score, value)
 
     def forward(self, x, meta_channel):
-        if not (isinstance(x, torch.Tensor) and isinstance(meta_channel, torch.Tensor)) or x.dim() != 4 or meta_channel.dim() != 4:
-            raise RuntimeError("SemanticNetworkWithFPN expects x[B,c,H,W] and meta_channel[B,m,H,W]")
-        if not x.is_cuda:
-            raise RuntimeError(f"semanticlidarunc_amd FPN runs on MI355X only: input is on '{x.device}' and there is no CPU fallback")
-        if x.shape[2] % 16 or x.shape[3] % 16:
-            raise RuntimeError("SemanticNetworkWithFPN needs H and W divisible by 16")
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("training of the FPN model is not on the HIP path yet; call .eval() (autograd is not recorded)")
-        x = x.contiguous().float()
-        meta = meta_channel.contiguous().float()
-        m1 = m2 = m3 = None
-        if self.multi_scale_meta:
-            m1, m2, m3 = ops.nearest_down(meta, 2), ops.nearest_down(meta, 4), ops.nearest_down(meta, 8)
-        xs = self._conv("stem", self.backbone.conv1, None, [ConvSource(x), ConvSource(meta)])       # bn1 is skipped by the reference stem
-        xs = ops.maxpool3s2(xs)
-        x1 = self._stage("layer1", self.layer1, xs, None)
-        x2 = self._stage("layer2", self.layer2, x1, m1)
-        x3 = self._stage("layer3", self.layer3, x2, m2)
-        x4 = self._stage("layer4", self.layer4, x3, m3)
+        x, meta = self._check_inputs(x, meta_channel)
+        x1, x2, x3, x4 = self._encode(x, meta)
         f4 = self._conv("fpn4", self.fpn_block4[0], self.fpn_block4[1], [ConvSource(x4)])
         f3 = self._conv("fpn3", self.fpn_block3[0], self.fpn_block3[1], [ConvSource(x3)])
         f2 = self._conv("fpn2", self.fpn_block2[0], self.fpn_block2[1], [ConvSource(x2)])

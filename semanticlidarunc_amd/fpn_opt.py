@@ -1,0 +1,142 @@
+"""The `semanticFCN_opt` variant of the ResNet-FPN segmenter on MI355X -- what the reference's `train_semantics.py:134` builds for
+`baseline: Reichert` (src/baselines/Reichert/semanticFCN_opt.py:109-455) -- for the resnet18 / resnet34 backbones.
+
+Same encoder as `fpn.SemanticNetworkWithFPN` (shared code); the head differs:
+  SpatialAttention (:73-85)   1x1 (C -> C/8, no bias) + ReLU -> 1x1 (-> 1) -> softmax over H*W -> x * w + x
+                              = two fused conv launches + `slu_spatial_softmax_gate`
+  UpsampleBlock (:10-28)      bilinear x8 / x4 / x2 (align_corners=False) -> conv3x3 (no bias) -> GroupNorm -> ReLU
+                              = `slu_bilinear_upsample` + one conv launch + `slu_groupnorm_fwd` (ReLU fused)
+  dropout_pyramid (:266)      nn.Dropout2d(0.1) on cat([x1, x2, x3, x4]): drawn by the real child on a [B,C,1,1] tensor of ones and folded
+                              into the first decoder conv as per-(sample, channel) input multipliers -- so MC-dropout
+                              (`utils.mc_dropout`) works on this model, unlike on `models/semanticFCN.py` which has no dropout
+  decoder (:286-296)          conv3x3 -> GN -> ReLU -> conv3x3 -> GN -> ReLU -> UpsampleBlock(x2) -> conv1x1: RAW LOGITS (no ELU)
+Contract kept: constructor keywords, `forward(x, meta) -> logits [B,num_classes,H,W]`, `state_dict` keys / shapes of the reference
+class (checked against it in tools/gen_golden_r02.py), genuine `nn.Dropout2d` / `nn.GroupNorm` children.  Inference only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .fpn import SemanticNetworkWithFPN as _FPNBase
+from .fpn import _RESNETS
+from .ops import ConvSource
+
+
+class UpsampleBlock(nn.Module):
+    """Interpolate -> 3x3 conv -> GroupNorm -> ReLU (module layout of the reference, :10-28)."""
+
+    def __init__(self, in_ch: int, out_ch: int, scale: int, mode: str = "bilinear", groups: int = 8):
+        super().__init__()
+        self.scale, self.mode = scale, mode
+        self.block = nn.Sequential(nn.Conv2d(in_ch, out_ch, 3, padding=1, bias=False), nn.GroupNorm(math.gcd(groups, out_ch) or 1, out_ch),
+                                   nn.ReLU(inplace=True))
+
+
+def GN(channels, groups=32):
+    g = min(groups, channels)
+    return nn.GroupNorm(math.gcd(g, channels) or 1, channels)
+
+
+class SpatialAttention(nn.Module):
+    def __init__(self, in_ch, reduction=8):
+        super().__init__()
+        hid = max(1, in_ch // reduction)
+        self.proj = nn.Conv2d(in_ch, hid, kernel_size=1, bias=False)
+        self.score = nn.Conv2d(hid, 1, kernel_size=1, bias=False)
+
+
+class SemanticNetworkWithFPN(_FPNBase):
+    def __init__(self, backbone="resnet18", input_channels=2, meta_channel_dim=3, interpolation_mode="nearest", num_classes=3,
+                 attention=True, multi_scale_meta=True):
+        nn.Module.__init__(self)
+        if backbone not in _RESNETS:
+            known = ("resnet50", "regnet_y_400mf", "regnet_y_800mf", "regnet_y_1_6gf", "regnet_y_3_2gf", "shufflenet_v2_x0_5", "shufflenet_v2_x1_0",
+                     "shufflenet_v2_x1_5", "shufflenet_v2_x2_0", "squeezenet1_0", "efficientnet_v2_s", "efficientnet_v2_m", "efficientnet_v2_l")
+            if backbone in known:
+                raise NotImplementedError(f"backbone '{backbone}' is not implemented on the HIP path yet (resnet18 / resnet34 are)")
+            raise ValueError("Invalid ResNet type. Supported types: 'resnet18', 'resnet34', 'resnet50', 'regnet_y_400mf','regnet_y_800mf', "
+                             "'regnet_y_1_6gf', 'regnet_y_3_2gf', 'shufflenet_v2_x0_5', 'shufflenet_v2_x1_0', 'shufflenet_v2_x1_5', "
+                             "'shufflenet_v2_x2_0.")
+        if interpolation_mode != "nearest":
+            raise NotImplementedError("only interpolation_mode='nearest' (the reference default) runs on the HIP path")
+        self.backbone_name, self.interpolation_mode = backbone, interpolation_mode
+        self.num_classes, self.attention, self.multi_scale_meta = num_classes, attention, multi_scale_meta
+        bc = self._build_encoder(backbone, input_channels, meta_channel_dim)
+        self.attention4, self.attention3 = SpatialAttention(bc[1]), SpatialAttention(bc[2])
+        self.attention2, self.attention1 = SpatialAttention(bc[3]), SpatialAttention(bc[4])
+        self.fpn_block4, self.fpn_block3 = self._fpn(bc[0], bc[1]), self._fpn(bc[1], bc[2])
+        self.fpn_block2, self.fpn_block1 = self._fpn(bc[2], bc[3]), self._fpn(bc[3], bc[4])
+        self.dropout_pyramid = nn.Dropout2d(p=0.1)
+        out_chs = [bc[1] // 8, bc[2] // 4, bc[3] // 2]
+        self.upsample_layer_x4 = UpsampleBlock(bc[1], out_chs[0], scale=8, mode="bilinear")
+        self.upsample_layer_x3 = UpsampleBlock(bc[2], out_chs[1], scale=4, mode="bilinear")
+        self.upsample_layer_x2 = UpsampleBlock(bc[3], out_chs[2], scale=2, mode="bilinear")
+        self.decoder_semantic = nn.Sequential(
+            nn.Conv2d(sum(out_chs) + bc[4], bc[4], 3, padding=1, bias=False), GN(bc[4]), nn.ReLU(inplace=True),
+            nn.Conv2d(bc[4], bc[4], 3, padding=1, bias=False), GN(bc[4]), nn.ReLU(inplace=True),
+            UpsampleBlock(bc[4], bc[4] // 2, scale=2),
+            nn.Conv2d(bc[4] // 2, num_classes, kernel_size=1))
+
+    # ---------------- head pieces ----------------
+    def _spatial_attention(self, name, att: SpatialAttention, x):
+        hid = self._conv(name + ".proj", att.proj, None, [ConvSource(x)], act="relu")
+        score = self._conv(name + ".score", att.score, None, [ConvSource(hid)], act="none")
+        return ops.spatial_softmax_gate(x, score)
+
+    def _upsample_block(self, name, up: UpsampleBlock, srcs_before_interp):
+        """UpsampleBlock.forward: the (single) input is interpolated, then conv -> GroupNorm -> ReLU."""
+        if up.mode != "bilinear":
+            raise NotImplementedError("UpsampleBlock: only mode='bilinear' (what the reference constructs) runs on the HIP path")
+        xi = ops.bilinear_upsample(srcs_before_interp, up.scale)
+        conv, gn = up.block[0], up.block[1]
+        y = self._conv(name, conv, None, [ConvSource(xi)], act="none")
+        return ops.groupnorm(y, gn.num_groups, gn.weight.detach(), gn.bias.detach(), gn.eps, relu=True, inplace=True)
+
+    def _pyramid_dropout(self, n, c, device, scale_override: Optional[torch.Tensor]):
+        """[n, c] multipliers of dropout_pyramid (None = identity), drawn by the real nn.Dropout2d child (its .training flag is what
+        utils.mc_dropout.set_dropout_mode toggles)."""
+        if scale_override is not None:
+            return scale_override.reshape(n, c).to(device=device, dtype=torch.float32).contiguous()
+        d = self.dropout_pyramid
+        if not d.training or d.p == 0.0:
+            return None
+        return d(torch.ones((n, c, 1, 1), dtype=torch.float32, device=device)).reshape(n, c)
+
+    def forward(self, x, meta_channel):
+        return self._forward(x, meta_channel, None)
+
+    def forward_with_dropout_scale(self, x, meta_channel, scale: torch.Tensor):
+        """forward() with the dropout_pyramid multipliers given explicitly ([B, C_pyramid] or [B, C_pyramid, 1, 1]); parity tests."""
+        return self._forward(x, meta_channel, scale)
+
+    def _forward(self, x, meta_channel, drop_scale):
+        x, meta = self._check_inputs(x, meta_channel)
+        x1, x2, x3, x4 = self._encode(x, meta)
+        f4 = self._conv("fpn4", self.fpn_block4[0], self.fpn_block4[1], [ConvSource(x4)])
+        f3 = self._conv("fpn3", self.fpn_block3[0], self.fpn_block3[1], [ConvSource(x3)])
+        f2 = self._conv("fpn2", self.fpn_block2[0], self.fpn_block2[1], [ConvSource(x2)])
+        f1 = self._conv("fpn1", self.fpn_block1[0], self.fpn_block1[1], [ConvSource(x1)])
+        if self.attention:
+            f4, f3 = self._spatial_attention("att4", self.attention4, f4), self._spatial_attention("att3", self.attention3, f3)
+            f2, f1 = self._spatial_attention("att2", self.attention2, f2), self._spatial_attention("att1", self.attention1, f1)
+        u4 = self._upsample_block("up4", self.upsample_layer_x4, f4)
+        u3 = self._upsample_block("up3", self.upsample_layer_x3, f3)
+        u2 = self._upsample_block("up2", self.upsample_layer_x2, f2)
+        # cat([x1, x2, x3, x4]) -> dropout_pyramid -> decoder conv: three sources (x1 | x2 | x3 + x4 share a buffer), multipliers per source
+        n = f1.shape[0]
+        c1, c2, c3, c4 = f1.shape[1], u2.shape[1], u3.shape[1], u4.shape[1]
+        s = self._pyramid_dropout(n, c1 + c2 + c3 + c4, f1.device, drop_scale)
+        u34 = torch.cat([u3, u4], dim=1)              # the fused conv takes up to three sources
+        sc = (None, None, None) if s is None else (s[:, :c1].contiguous(), s[:, c1:c1 + c2].contiguous(), s[:, c1 + c2:].contiguous())
+        d = self.decoder_semantic
+        y = self._conv("dec0", d[0], None, [ConvSource(f1, sc[0]), ConvSource(u2, sc[1]), ConvSource(u34, sc[2])], act="none")
+        y = ops.groupnorm(y, d[1].num_groups, d[1].weight.detach(), d[1].bias.detach(), d[1].eps, relu=True, inplace=True)
+        y = self._conv("dec1", d[3], None, [ConvSource(y)], act="none")
+        y = ops.groupnorm(y, d[4].num_groups, d[4].weight.detach(), d[4].bias.detach(), d[4].eps, relu=True, inplace=True)
+        y = self._upsample_block("dec_up", d[6], y)
+        return self._conv("dec_out", d[7], None, [ConvSource(y)], act="none")

@@ -661,6 +661,50 @@ def row_softmax_mul(score, value):
 
 # ------------------------------------------------------------------------------------------------
 # AUROC of error detection (metrics/auroc.py of the reference)
+def bilinear_upsample(x: torch.Tensor, scale: int) -> torch.Tensor:
+    """F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False) on the device."""
+    _req(x, "x")
+    if x.dim() != 4 or int(scale) < 1:
+        raise RuntimeError("bilinear_upsample: NCHW tensor and an integer scale >= 1 expected")
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h * int(scale), w * int(scale)), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_bilinear_upsample(x.data_ptr(), y.data_ptr(), n, c, h, w, int(scale), _stream()), "slu_bilinear_upsample")
+    return y
+
+
+def groupnorm(x: torch.Tensor, groups: int, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5, relu: bool = False,
+              inplace: bool = False) -> torch.Tensor:
+    """nn.GroupNorm(groups, C, eps)(x) [+ ReLU] for NCHW x."""
+    _req(x, "x")
+    if x.dim() != 4 or x.shape[1] % int(groups):
+        raise RuntimeError(f"groupnorm: NCHW input with C divisible by groups={groups} expected, got {tuple(x.shape)}")
+    n, c, h, w = x.shape
+    for t, nme in ((gamma, "gamma"), (beta, "beta")):
+        if t is not None:
+            _req(t, nme)
+            if t.numel() != c:
+                raise RuntimeError(f"{nme}: expected {c} elements")
+    stats = torch.empty((2, n * int(groups)), dtype=torch.float32, device=x.device)
+    y = x if inplace else torch.empty_like(x)
+    check(_lib.load().slu_groupnorm_fwd(x.data_ptr(), _ptr(gamma), _ptr(beta), n, c, h * w, int(groups), float(eps), 1 if relu else 0, stats[0].data_ptr(),
+                                        stats[1].data_ptr(), y.data_ptr(), _stream()), "slu_groupnorm_fwd")
+    return y
+
+
+def spatial_softmax_gate(x: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
+    """x * softmax(score over H*W) + x  (SpatialAttention of semanticFCN_opt): x [N,C,H,W], score [N,1,H,W]."""
+    _req(x, "x")
+    _req(score, "score")
+    if x.dim() != 4 or tuple(score.shape) != (x.shape[0], 1, x.shape[2], x.shape[3]):
+        raise RuntimeError(f"spatial_softmax_gate: x [N,C,H,W] / score [N,1,H,W] expected, got {tuple(x.shape)} / {tuple(score.shape)}")
+    n, c, h, w = x.shape
+    stats = torch.empty(2 * n, dtype=torch.float32, device=x.device)
+    out = torch.empty_like(x)
+    check(_lib.load().slu_spatial_softmax_gate(x.data_ptr(), score.data_ptr(), stats.data_ptr(), out.data_ptr(), n, c, h * w, _stream()),
+          "slu_spatial_softmax_gate")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 AUROC_MODES = {"alpha": 0, "logits": 1, "probs": 2}
 AUROC_SCORES = {"entropy": 0, "entropy_norm": 1, "mi": 2, "mi_norm": 3, "1-maxprob": 4}

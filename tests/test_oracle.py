@@ -334,3 +334,34 @@ def test_kitti_sample_and_projection_options_match_reference():
                     ("farthest_bins_h_range", dict(sort_largest_first=True, bins_h=beams, theta_range=(-0.45, 0.05)))):
         img, _, th, _ = oproj.spherical_projection(cloud, 32, 256, **kw)
         assert np.array_equal(img, g[f"proj:{tag}:img"]) and np.allclose(th, g[f"proj:{tag}:theta"], rtol=0, atol=0)
+
+
+def test_fpn_opt_oracle_matches_reference_golden():
+    """f-4 (golden: tools/gen_golden_r02.py fpn_opt, the reference's own semanticFCN_opt head wiring on this repo's state_dict)."""
+    from oracle import fpn_opt as ofpo
+    from semanticlidarunc_amd.fpn_opt import SemanticNetworkWithFPN
+    from semanticlidarunc_amd.testing import randomize_bn_
+    for tag, kw in (("resnet18_m6_c20", dict(backbone="resnet18", input_channels=2, meta_channel_dim=6, num_classes=20)),
+                    ("resnet34_m3_c21_noatt", dict(backbone="resnet34", input_channels=2, meta_channel_dim=3, num_classes=21, attention=False,
+                                                   multi_scale_meta=False))):
+        g = golden("fpn_opt_" + tag)
+        torch.manual_seed(0)
+        m = randomize_bn_(SemanticNetworkWithFPN(**kw), 3).eval()
+        with torch.no_grad():
+            gg = torch.Generator().manual_seed(9)
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.GroupNorm):
+                    mod.weight.copy_(torch.rand(mod.num_channels, generator=gg) + 0.5)
+                    mod.bias.copy_(torch.randn(mod.num_channels, generator=gg) * 0.1)
+        sd = m.state_dict()
+        dig = [sum(float(v.double().sum()) for v in sd.values() if v.is_floating_point()), sum(float(v.double().abs().sum()) for v in sd.values() if v.is_floating_point())]
+        assert np.allclose(dig, g["sd_digest"], rtol=1e-12)
+        with torch.no_grad():
+            y = ofpo.fpn_opt_forward(sd, _t(g["x"]), _t(g["meta"]), kw["backbone"], kw.get("attention", True), kw.get("multi_scale_meta", True))
+            yd = ofpo.fpn_opt_forward(sd, _t(g["x"]), _t(g["meta"]), kw["backbone"], kw.get("attention", True), kw.get("multi_scale_meta", True),
+                                      dropout_scale=_t(g["dropout_scale"]))
+        assert float((y - _t(g["out"])).abs().max()) <= 1e-5 and float((yd - _t(g["out_dropout"])).abs().max()) <= 1e-5
+    keys = json.load(open(os.path.join(GOLDEN, "fpn_opt_resnet18_state_dict_keys.json")))
+    torch.manual_seed(0)
+    mine = SemanticNetworkWithFPN("resnet18", 2, 6, num_classes=20).state_dict()
+    assert list(mine.keys()) == list(keys.keys()) and all(list(v.shape) == keys[k] for k, v in mine.items())

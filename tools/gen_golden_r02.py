@@ -155,7 +155,66 @@ def gen_kitti():
     save("kitti_sample_16000_32x256", **out)
 
 
-GENERATORS = {"ece": gen_ece, "kitti": gen_kitti}
+def gen_fpn_opt():
+    """f-4: baselines/Reichert/semanticFCN_opt.py (resnet18 / resnet34) through the stub torchvision.models that serves oracle.fpn's restated
+    BasicBlock ResNet: the reference's OWN head wiring (SpatialAttention, UpsampleBlock + GroupNorm, dropout_pyramid, GN decoder) runs on
+    the state_dict of this repo's class; the Dropout2d of the pyramid is pinned by instrumenting the reference module with a fixed
+    multiplier."""
+    import json
+    from oracle import fpn as ofpn, fpn_opt as ofpo
+    from semanticlidarunc_amd.fpn_opt import SemanticNetworkWithFPN as MyOpt
+    from semanticlidarunc_amd.testing import randomize_bn_
+    tv = types.ModuleType("torchvision")
+    tv.models = ofpn.torchvision_models_stub()
+    sys.modules["torchvision"], sys.modules["torchvision.models"] = tv, tv.models
+    from baselines.Reichert.semanticFCN_opt import SemanticNetworkWithFPN as RefOpt        # the reference's own wiring
+    for tag, kw, shape in (("resnet18_m6_c20", dict(backbone="resnet18", input_channels=2, meta_channel_dim=6, num_classes=20), (2, 32, 128)),
+                           ("resnet34_m3_c21_noatt", dict(backbone="resnet34", input_channels=2, meta_channel_dim=3, num_classes=21,
+                                                          attention=False, multi_scale_meta=False), (1, 16, 64))):
+        torch.manual_seed(0)
+        mine = randomize_bn_(MyOpt(**kw), 3).eval()
+        with torch.no_grad():                                # non-trivial GroupNorm affines
+            g = torch.Generator().manual_seed(9)
+            for mod in mine.modules():
+                if isinstance(mod, torch.nn.GroupNorm):
+                    mod.weight.copy_(torch.rand(mod.num_channels, generator=g) + 0.5)
+                    mod.bias.copy_(torch.randn(mod.num_channels, generator=g) * 0.1)
+        ref = RefOpt(**kw)
+        sdf = mine.state_dict()
+        assert list(sdf.keys()) == list(ref.state_dict().keys()), "state_dict key order differs from the reference class"
+        assert all(tuple(a.shape) == tuple(b.shape) for a, b in zip(sdf.values(), ref.state_dict().values()))
+        assert [type(m).__name__ for m in mine.modules() if isinstance(m, (torch.nn.Dropout2d, torch.nn.GroupNorm))] == \
+               [type(m).__name__ for m in ref.modules() if isinstance(m, (torch.nn.Dropout2d, torch.nn.GroupNorm))]
+        ref.load_state_dict(sdf)
+        ref.eval()
+        g = torch.Generator().manual_seed(51)
+        xf = torch.randn(shape[0], 2, shape[1], shape[2], generator=g) * torch.tensor([20.0, 0.3]).view(1, 2, 1, 1)
+        mf = torch.randn(shape[0], kw["meta_channel_dim"], shape[1], shape[2], generator=g) * 5.0
+        with torch.no_grad():
+            yr = ref(xf, mf)
+            yo = ofpo.fpn_opt_forward(sdf, xf, mf, kw["backbone"], kw.get("attention", True), kw.get("multi_scale_meta", True))
+            print(f"FPN-opt {tag}: |oracle - reference| = {float((yr - yo).abs().max()):.3e}  (|logit| max {float(yr.abs().max()):.2f})")
+            assert float((yr - yo).abs().max()) <= 1e-5 * max(1.0, float(yr.abs().max()))
+            # the pyramid dropout with a fixed multiplier: replace the reference's Dropout2d child by a module that applies it
+            cpyr = ref.decoder_semantic[0].in_channels
+            scale = (torch.rand(shape[0], cpyr, 1, 1, generator=g) > 0.1).float() / 0.9
+            class Fixed(torch.nn.Module):
+                def forward(self, t):
+                    return t * scale
+            ref.dropout_pyramid = Fixed()
+            yr_d = ref(xf, mf)
+            yo_d = ofpo.fpn_opt_forward(sdf, xf, mf, kw["backbone"], kw.get("attention", True), kw.get("multi_scale_meta", True), dropout_scale=scale)
+            assert float((yr_d - yo_d).abs().max()) <= 1e-5 * max(1.0, float(yr.abs().max()))
+        save("fpn_opt_" + tag, x=xf, meta=mf, out=yr, out_dropout=yr_d, dropout_scale=scale[:, :, 0, 0],
+             sd_digest=np.array([sum(float(v.double().sum()) for v in sdf.values() if v.is_floating_point()),
+                                 sum(float(v.double().abs().sum()) for v in sdf.values() if v.is_floating_point())]))
+    with open(os.path.join(OUT, "fpn_opt_resnet18_state_dict_keys.json"), "w") as f:
+        torch.manual_seed(0)
+        json.dump({k: list(v.shape) for k, v in RefOpt("resnet18", 2, 6, num_classes=20).state_dict().items()}, f, indent=0)
+    print("  oracle.fpn_opt == reference baselines.Reichert.semanticFCN_opt (head wiring; backbone internals restated)")
+
+
+GENERATORS = {"ece": gen_ece, "kitti": gen_kitti, "fpn_opt": gen_fpn_opt}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(GENERATORS)):
