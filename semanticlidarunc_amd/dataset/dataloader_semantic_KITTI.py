@@ -47,7 +47,7 @@ class SemanticKitti(Dataset):
     def gpu_loader(self, device="cuda", **loader_kwargs):
         """DataLoader(num_workers > 0)-compatible device pipeline over this dataset: yields (range, reflectivity, xyz, normals, semantics)
         batches that already live on `device`."""
-        cls = gpu_pipeline.projecting_loader_class(lambda ds: ds.projector(device), lambda ds: ds._raw if isinstance(ds, SemanticKitti) else None)
+        cls = gpu_pipeline.projecting_loader_class(lambda ds: ds.projector(device), lambda ds: getattr(ds, "_raw", None) if hasattr(ds, "projector") else None)
         return cls(self, **loader_kwargs)
 
 

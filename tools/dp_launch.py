@@ -10,7 +10,8 @@ three seams per rank before calling the script's `main(args)`:
 
   1. `DataLoader` as seen by the script (train_semantics.py:4): a `shuffle=True` loader gets a `ShardedSampler` (disjoint shards of
      one seeded permutation, equal sizes); the `shuffle=False` validation loader is left whole -- every rank evaluates the full
-     validation set on identical weights, so all ranks log identical metrics and no metric exchange is needed.
+     validation set on identical weights, so all ranks log identical metrics and no metric exchange is needed.  With
+     `--gpu-projection` the loader is also the device-projecting one of dataset/gpu_pipeline.py.
   2. `Trainer.__init__` (models/trainer.py:167): after the reference's constructor has moved the model to the rank's GPU,
      parameters and buffers are broadcast from rank 0 and ONE flat gradient all-reduce is attached to the optimizer as a pre-step
      hook (`distributed.FlatGradAllReduce`): the Trainer's own step becomes a synchronous data-parallel step.
@@ -40,6 +41,9 @@ def parse(argv=None):
     ap.add_argument("--script", required=True, help="path to the reference's src/train_semantics.py (or any script with the same main(args))")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL with a GPU, gloo without)")
     ap.add_argument("--seed", type=int, default=0, help="seed of the sharded permutation")
+    ap.add_argument("--gpu-projection", action="store_true",
+                    help="SemanticKitti loaders: workers only read files, the main process decodes / projects whole batches on the GPU "
+                         "(semanticlidarunc_amd/dataset/gpu_pipeline.py); other datasets keep the stock loader")
     ap.add_argument("--trainer-module", default="models.trainer", help="module that defines Trainer (imported with the script's directory on sys.path)")
     # the script's own four flags (train_semantics.py:343-364); its `type=bool` flags treat every non-empty string as True
     ap.add_argument("--visualization", type=_str2bool, default=False)
@@ -49,12 +53,14 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
-def sharded_loader_class(rank: int, world: int, seed: int):
-    """A DataLoader subclass for the script's namespace: same constructor, a shuffling loader becomes a sharded one."""
+def sharded_loader_class(rank: int, world: int, seed: int, base=None):
+    """A DataLoader subclass for the script's namespace: same constructor, a shuffling loader becomes a sharded one.
+    `base`: the loader class to derive from (default torch's; --gpu-projection passes the device-projecting loader)."""
     import torch.utils.data as tud
     from semanticlidarunc_amd.distributed import ShardedSampler
+    base = base or tud.DataLoader
 
-    class ShardedDataLoader(tud.DataLoader):
+    class ShardedDataLoader(base):
         def __init__(self, dataset=None, *args, **kwargs):
             if dataset is None:
                 dataset = kwargs.pop("dataset")
@@ -115,7 +121,16 @@ def main(argv=None):
     spec = importlib.util.spec_from_file_location("_slu_dp_train_script", script)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)                                # __name__ != "__main__": the script's argparse block does not run
-    mod.DataLoader = sharded_loader_class(rank, world, a.seed)  # seam 1
+    base = None
+    if a.gpu_projection:
+        # DataLoader workers only read the .bin / .label files; decode, id_map, rotation, spherical projection, flip,
+        # range and normals run as HIP kernels on whole batches in this (the rank's main) process
+        from semanticlidarunc_amd.dataset import gpu_pipeline
+        # duck-typed: in drop-in mode the script's dataset class comes from the module named `dataset.dataloader_semantic_KITTI`
+        # (this repo's mirror under the reference's import path), a different module object than the package-qualified one
+        base = gpu_pipeline.projecting_loader_class(lambda ds: ds.projector(torch.device("cuda", local_rank) if torch.cuda.is_available() else "cpu"),
+                                                    lambda ds: getattr(ds, "_raw", None) if hasattr(ds, "projector") else None)
+    mod.DataLoader = sharded_loader_class(rank, world, a.seed, base)  # seam 1
     if a.mode == "train":
         install_trainer_hooks(importlib.import_module(a.trainer_module).Trainer)     # seams 2, 3
     args = argparse.Namespace(visualization=a.visualization and rank == 0, with_logging=a.with_logging and rank == 0,
