@@ -86,13 +86,103 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     }
   }
 
+  // The four waves of the workgroup worked on the same (cob, cib) block: their partial sums meet in LDS tap by tap and ONE wave adds
+  // each tap's total to dWp -- float atomics execute at the memory side at ~one 256-byte wave-instruction per 50 ns per CU
+  // (MI355X_MICROARCH.md), so a wave-private flush of T x 16 of them cost more than the MFMAs of a short run.
   // D[i = co][j = ci]: lane & 31 = ci, register/half = co
+  __shared__ float s_red[4][16][64];
 #pragma unroll
-  for (int t = 0; t < T; ++t)
+  for (int t = 0; t < T; ++t) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      atomicAdd(&dWp[((size_t)co * T + t) * Cip + cib * 32 + jj], acc[t][r]);
+    for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[t][r];
+    __syncthreads();
+    if (wave == (t & 3)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = (s_red[0][r][lane] + s_red[1][r][lane]) + (s_red[2][r][lane] + s_red[3][r][lane]);
+        const int co = cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        atomicAdd(&dWp[((size_t)co * T + t) * Cip + cib * 32 + jj], v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// 1x1 convs: a plain GEMM dW[co][ci] = sum_pix da[pix][co] * in[pix][ci].  One (32 x 32) block per wave needs two loads per MFMA and is
+// latency-bound; here a wave owns MT x NT blocks (MT + NT loads per MT * NT MFMAs) and U K-steps of operands are in flight.
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(const float* __restrict__ da_t, const float* __restrict__ in_t, long long npix, int Cop,
+                                                          int Cip, float* __restrict__ dWp) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hh = lane >> 5, jj = lane & 31;
+  const int cob0 = blockIdx.y * MT, cib0 = blockIdx.z * NT;
+  const int ncob = Cop / 32, ncib = Cip / 32;
+  const long long npairs = npix / 2;
+  const long long nruns = (npairs + kRun - 1) / kRun;
+  const long long worker = (long long)blockIdx.x * 4 + wave, nworkers = (long long)gridDim.x * 4;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // blocks past the last one read block 0 and are never stored
+  const float* abase[MT];
+  const float* bbase[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) abase[i] = da_t + (size_t)(cob0 + i < ncob ? cob0 + i : 0) * 32 + jj;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bbase[j] = in_t + (size_t)(cib0 + j < ncib ? cib0 + j : 0) * 32 + jj;
+
+  for (long long run = worker; run < nruns; run += nworkers) {
+    const long long q0 = run * kRun;
+    const long long q1 = (q0 + kRun < npairs) ? q0 + kRun : npairs;
+    for (long long q = q0; q < q1; q += U) {
+      float a[U][MT], b[U][NT];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool live = q + u < q1;
+        const size_t pix = (size_t)(2 * (live ? q + u : q0) + hh);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float v = abase[i][pix * Cop];
+          a[u][i] = live ? v : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float v = bbase[j][pix * Cip];
+          b[u][j] = live ? v : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  __shared__ float s_red[4][16][64];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[i][j][r];
+      __syncthreads();
+      if (wave == ((i * NT + j) & 3) && cob0 + i < ncob && cib0 + j < ncib) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = (s_red[0][r][lane] + s_red[1][r][lane]) + (s_red[2][r][lane] + s_red[3][r][lane]);
+          const int co = (cob0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          atomicAdd(&dWp[(size_t)co * Cip + (cib0 + j) * 32 + jj], v);
+        }
+      }
+      __syncthreads();
     }
 }
 
@@ -123,12 +213,34 @@ template <int KS, int DIL, int PAD>
 int launch_wgrad(const float* da_t, const float* in_t, int N, int H, int W, int Cop, int Cip, float* dWp, hipStream_t st) {
   const int nb = (Cop / 32) * (Cip / 32);
   const long long nruns = ((long long)N * H * W / 2 + kRun - 1) / kRun;
-  long long gx = 1024 / nb;
+  // two resident workgroups per CU over all channel-block pairs (2 waves per SIMD): every wave then walks many pixel runs before its
+  // partial sums are flushed, instead of four queued waves of workgroups that each flush after a couple of runs
+  long long gx = 512 / nb;
   if (gx < 1) gx = 1;
   if (gx * 4 > nruns) gx = (nruns + 3) / 4;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL((wgrad_kernel<KS, DIL, PAD>), dim3((unsigned)gx, Cop / 32, Cip / 32), dim3(256), 0, st, da_t, in_t, N, H, W, Cop, Cip, dWp);
   SLU_CHECK_LAUNCH();
+}
+
+template <int MT, int NT>
+int launch_wgrad1x1_t(const float* da_t, const float* in_t, long long npix, int Cop, int Cip, float* dWp, hipStream_t st) {
+  const int gy = (Cop / 32 + MT - 1) / MT, gz = (Cip / 32 + NT - 1) / NT;
+  const long long nruns = (npix / 2 + kRun - 1) / kRun;
+  long long gx = 1024 / ((long long)gy * gz);            // ~4 workgroups per CU: these waves are light on registers and live on occupancy
+  if (gx < 1) gx = 1;
+  if (gx * 4 > nruns) gx = (nruns + 3) / 4;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((wgrad1x1_kernel<MT, NT>), dim3((unsigned)gx, gy, gz), dim3(256), 0, st, da_t, in_t, npix, Cop, Cip, dWp);
+  SLU_CHECK_LAUNCH();
+}
+
+int launch_wgrad1x1(const float* da_t, const float* in_t, long long npix, int Cop, int Cip, float* dWp, hipStream_t st) {
+  const int ncob = Cop / 32, ncib = Cip / 32;
+  if (ncob >= 2 && ncib >= 2) return launch_wgrad1x1_t<2, 2>(da_t, in_t, npix, Cop, Cip, dWp, st);
+  if (ncob >= 2) return launch_wgrad1x1_t<2, 1>(da_t, in_t, npix, Cop, Cip, dWp, st);
+  if (ncib >= 2) return launch_wgrad1x1_t<1, 2>(da_t, in_t, npix, Cop, Cip, dWp, st);
+  return launch_wgrad1x1_t<1, 1>(da_t, in_t, npix, Cop, Cip, dWp, st);
 }
 
 }  // namespace
@@ -147,7 +259,7 @@ extern "C" int slu_conv2d_wgrad(const float* da_t, const float* in_t, int N, int
   hipStream_t st = slu_stream(stream);
   if (hipMemsetAsync(dWp, 0, slu_wgrad_packed_floats(Cout, Cin, ksize) * sizeof(float), st) != hipSuccess) return SLU_ELAUNCH;
   int rc;
-  if (ksize == 1 && dil == 1 && pad == 0) rc = launch_wgrad<1, 1, 0>(da_t, in_t, N, H, W, Cop, Cip, dWp, st);
+  if (ksize == 1 && dil == 1 && pad == 0) rc = launch_wgrad1x1(da_t, in_t, (long long)N * H * W, Cop, Cip, dWp, st);
   else if (ksize == 3 && dil == 1 && pad == 1) rc = launch_wgrad<3, 1, 1>(da_t, in_t, N, H, W, Cop, Cip, dWp, st);
   else if (ksize == 3 && dil == 2 && pad == 2) rc = launch_wgrad<3, 2, 2>(da_t, in_t, N, H, W, Cop, Cip, dWp, st);
   else if (ksize == 2 && dil == 2 && pad == 1) rc = launch_wgrad<2, 2, 1>(da_t, in_t, N, H, W, Cop, Cip, dWp, st);

@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Per-shape timing of the weight-gradient kernel (training path, BASELINE configs[1]: batch 4 of 64x2048): python tools/wgrad_bench.py [B]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from semanticlidarunc_amd import ops  # noqa: E402
+
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+dev = torch.device("cuda:0")
+# (cin, cout, k, dil, pad, H, W) of SalsaNext's conv layers, one per distinct shape
+SHAPES = [(5, 32, 1, 1, 0, 64, 2048), (32, 32, 3, 1, 1, 64, 2048), (32, 32, 3, 2, 2, 64, 2048), (32, 64, 3, 1, 1, 64, 2048), (64, 64, 3, 2, 2, 64, 2048),
+          (64, 64, 2, 2, 1, 64, 2048), (192, 64, 1, 1, 0, 64, 2048), (80, 32, 3, 1, 1, 64, 2048), (96, 32, 1, 1, 0, 64, 2048),
+          (64, 128, 3, 1, 1, 32, 1024), (128, 128, 3, 2, 2, 32, 1024), (128, 128, 2, 2, 1, 32, 1024), (384, 128, 1, 1, 0, 32, 1024), (160, 64, 3, 1, 1, 32, 1024),
+          (128, 256, 3, 1, 1, 16, 512), (256, 256, 3, 2, 2, 16, 512), (768, 256, 1, 1, 0, 16, 512), (288, 128, 3, 1, 1, 16, 512),
+          (256, 256, 3, 1, 1, 8, 256), (256, 256, 3, 2, 2, 8, 256), (320, 128, 3, 1, 1, 8, 256), (256, 256, 3, 2, 2, 4, 128), (768, 256, 1, 1, 0, 4, 128)]
+tot = 0.0
+for cin, cout, k, dil, pad, h, w in SHAPES:
+    cop, cip = (cout + 31) // 32 * 32, (cin + 31) // 32 * 32
+    da = torch.randn(b, h * w, cop, device=dev)
+    xin = torch.randn(b, h * w, cip, device=dev)
+    for _ in range(2):
+        ops.conv2d_wgrad(da, xin, b, h, w, cout, cin, k, dil, pad)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ops.conv2d_wgrad(da, xin, b, h, w, cout, cin, k, dil, pad)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 5 * 1e3
+    fl = 2.0 * cin * cout * k * k * b * h * w
+    tot += us
+    print(f"{cin:4d}->{cout:3d} k{k}d{dil} {h:3d}x{w:4d}  {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s ({fl / us / 1e6 / 157.3 * 100:5.1f} % of fp32 MFMA peak)", flush=True)
+print(f"sum {tot:.0f} us")
