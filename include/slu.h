@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 18
+#define SLU_ABI_VERSION 20
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -80,6 +80,9 @@ typedef struct slu_conv_desc {   /* HOST struct */
   const float* resid;    /* [N, Cout, H, W] or NULL                                              */
   float* out;            /* [N, Cout, H, W]                                                      */
   int32_t precision;     /* SLU_CONV_FP32 (exact fp32 MFMA) or SLU_CONV_F16X3 (split-fp16, see below)             */
+  double* stats;         /* NULL, or f64 [2][Cout] (zero it first): the kernel adds the per-channel sum and sum of squares of the values it
+                            stores -- the batch statistics of a train-mode BatchNorm that follows (SalsaNext.py:30-36) without a second pass
+                            over the output.  SLU_CONV_FP32 only.                                                                        */
 } slu_conv_desc;
 
 /* precision of the multiply-accumulate inside slu_conv2d_fwd (inputs, outputs and accumulation are fp32 either way):

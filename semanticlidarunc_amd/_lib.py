@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 18
+ABI_VERSION = 20
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("bn_a", C.c_void_p), ("bn_b", C.c_void_p),
         ("resid", C.c_void_p), ("out", C.c_void_p),
         ("precision", C.c_int32),
+        ("stats", C.c_void_p),
     ]
 
 

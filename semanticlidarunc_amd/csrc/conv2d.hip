@@ -39,6 +39,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
   __shared__ __attribute__((aligned(16))) float s_in[CK * PLANE];
   __shared__ __attribute__((aligned(16))) float s_w[MBLK * KSTEPS * 64];
   __shared__ float s_epi[3 * MBLK * 32];          // bias | bn_a | bn_b of the workgroup's output channels
+  __shared__ double s_stat[2 * MBLK * 32];        // sum | sum of squares of the stored values per output channel (a.stats); fp64 so that
+                                                  // the order in which the waves arrive cannot change the result at fp32 level
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -71,6 +73,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
     s_epi[tid] = (ok && a.bias) ? a.bias[co] : 0.0f;
     s_epi[MBLK * 32 + tid] = (ok && a.bn_a) ? a.bn_a[co] : 1.0f;
     s_epi[2 * MBLK * 32 + tid] = (ok && a.bn_a) ? a.bn_b[co] : 0.0f;
+    s_stat[tid] = 0.0;
+    s_stat[MBLK * 32 + tid] = 0.0;
   }
 
   const int hh = lane >> 5, jj = lane & 31;
@@ -166,9 +170,13 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
   const bool act_late = (a.has_act & 4) != 0, act_tanh = act_kind == 2;
   const float slope_pre = (act_kind == 1 && !act_late) ? a.slope : 1.0f;
   const float slope_post = (act_kind == 1 && act_late) ? a.slope : 1.0f;
+  const bool want_stats = a.stats != nullptr;      // wave-uniform
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
     const int ml = wm * MB + i;               // channel block inside the workgroup tile
+    float ssum[16], ssq[16];                  // this lane's share of the batch statistics (its NB pixels of 16 channels)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.0f;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int gy = y0 + wn * RPW + (b >> 1), gx = x0 + (b & 1) * 32 + jj;
@@ -186,6 +194,32 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         if (resid) v += resid[o];
         v = v > 0.0f ? v : v * slope_post;
         if (ok) out[o] = v;
+        if (want_stats && ok) { ssum[r] += v; ssq[r] += v * v; }
+      }
+    }
+    if (want_stats) {
+      // the 32 lanes of a half hold 32 pixels of the same 16 channels: butterfly over them, lane 0 of each half adds the tile's share
+      // to the workgroup's LDS accumulators (float), which go out as one double atomic per channel at the end
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s1 = ssum[r], s2 = ssq[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (jj == 0) {
+          const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          atomicAdd(&s_stat[cl], (double)s1);
+          atomicAdd(&s_stat[MBLK * 32 + cl], (double)s2);
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < MBLK * 32) {
+      const int co = mblk0 * 32 + tid;
+      if (co < a.Cout) {
+        atomicAdd(&a.stats[co], s_stat[tid]);
+        atomicAdd(&a.stats[a.Cout + co], s_stat[MBLK * 32 + tid]);
       }
     }
   }

@@ -34,6 +34,7 @@ struct ConvArgs {
   int has_act;
   int vec;  // W % 4 == 0 and every base pointer 16-byte aligned: float4 staging path
   int gen;  // some source is read through PixelShuffle or carries a multiplier
+  double* stats;  // nullable: [2][Cout] per-channel sum / sum of squares of the stored output, accumulated (train-mode BatchNorm)
 };
 
 // Which source feeds conv-input channel cg (sources are channel-concatenated).
@@ -186,7 +187,7 @@ inline int fill_args(const slu_conv_desc* d, ConvArgs& a) {
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
   a.nchunks = (d->Cin + d->ck - 1) / d->ck;
   a.nmblk = (d->Cout + 31) / 32;
-  a.wpack = d->wpack; a.bias = d->bias; a.bn_a = d->bn_a; a.bn_b = d->bn_b; a.resid = d->resid; a.out = d->out;
+  a.wpack = d->wpack; a.bias = d->bias; a.bn_a = d->bn_a; a.bn_b = d->bn_b; a.resid = d->resid; a.out = d->out; a.stats = d->stats;
   if (d->has_act < 0 || d->has_act > 5 || d->has_act == 3 || d->has_act == 4) return SLU_EINVAL;   // tanh has no late form
   a.slope = d->slope; a.has_act = d->has_act;
   a.vec = (d->W % 4 == 0);

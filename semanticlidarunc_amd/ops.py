@@ -114,7 +114,8 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
                  bias: Optional[torch.Tensor] = None, slope: Optional[float] = None,
                  bn_a: Optional[torch.Tensor] = None, bn_b: Optional[torch.Tensor] = None,
                  resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                 precision: str = "fp32", act: Optional[str] = None, act_after_resid: bool = False) -> torch.Tensor:
+                 precision: str = "fp32", act: Optional[str] = None, act_after_resid: bool = False,
+                 stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = resid + bn_a * leaky(conv(cat(srcs)) + bias) + bn_b   (see slu_conv2d_fwd).
     precision 'fp32' (exact, wpack from pack_conv_weight) or 'f16x3' (split-fp16, wpack from pack_conv_weight_f16x3)."""
     if precision not in PRECISIONS:
@@ -201,6 +202,12 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
         d.has_act |= 4
     d.bn_a, d.bn_b, d.resid, d.out = _ptr(bn_a), _ptr(bn_b), _ptr(resid), out.data_ptr()
     d.precision = PRECISIONS[precision]
+    if stats is not None:
+        # per-channel sum / sum of squares of the stored output, added into `stats` (f64 [2, Cout], zeroed by the caller)
+        _req(stats, "stats", torch.float64)
+        if tuple(stats.shape) != (2, cout) or precision != "fp32":
+            raise RuntimeError("stats: expected a float64 [2, Cout] tensor with precision='fp32'")
+        d.stats = stats.data_ptr()
     if TIMING is None:
         check(lib.slu_conv2d_fwd(C.byref(d), _stream()), "slu_conv2d_fwd")
         return out

@@ -218,3 +218,18 @@ def test_full_size_training_step_against_oracle(cuda, train_precision):
         cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
         assert cos >= 0.999, (k, cos)
         assert abs(float(a.norm()) / float(b.norm()) - 1.0) <= 0.03, k
+
+
+def test_fused_bn_statistics(cuda):
+    """Training-path fusion: the conv kernel's own per-channel sum / sum of squares of what it stores == slu_bn_stats of its output."""
+    g = torch.Generator().manual_seed(12)
+    for cin, cout, k, dil, pad, h, w in ((32, 32, 3, 1, 1, 24, 200), (48, 80, 3, 2, 2, 16, 96), (64, 20, 1, 1, 0, 9, 70), (32, 64, 2, 2, 1, 8, 64)):
+        x = torch.randn(3, cin, h, w, generator=g).to(cuda)
+        wgt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(cuda)
+        bias = torch.randn(cout, generator=g).to(cuda)
+        stats = torch.zeros((2, cout), dtype=torch.float64, device=cuda)
+        y = ops.conv2d_fused([ConvSource(x)], ops.pack_conv_weight(wgt), cout, k, dil, pad, bias=bias, slope=0.01, stats=stats)
+        s, q = ops.bn_stats(y)
+        assert float(((stats[0] - s).abs() / (s.abs() + 1.0)).max()) <= 1e-5 and float(((stats[1] - q).abs() / q).max()) <= 1e-5
+        ref = y.double()
+        assert float(((stats[0] - ref.sum((0, 2, 3))).abs() / (ref.abs().sum((0, 2, 3)) + 1.0)).max()) <= 1e-6
