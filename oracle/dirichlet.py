@@ -82,14 +82,20 @@ def loss_mse(alpha, target, ignore_index=None, eps=1e-8):
     return _masked_mean(((y - p) ** 2 + var).sum(dim=1), target, ignore_index)
 
 
-def loss_kl_off_uniform(alpha, target, ignore_index=None, eps=1e-8):
+def loss_kl_off_uniform(alpha, target, ignore_index=None, eps=1e-8, with_conf_weighting=False, gamma=1.0):
+    """losses/regularizers.py:291-389; with_conf_weighting (:375-385): per-pixel weight (1 - p_y)^gamma, detached, mean over max(sum w, 1)."""
     valid = torch.ones_like(target, dtype=torch.bool) if ignore_index is None else target != ignore_index
     y = torch.zeros_like(alpha).scatter_(1, target.unsqueeze(1), 1.0)
     at = (y + (1.0 - y) * alpha).permute(0, 2, 3, 1).reshape(-1, alpha.shape[1])[valid.reshape(-1)]
     a = at.clamp_min(eps)
     s = a.sum(dim=1, keepdim=True)
     kl = torch.lgamma(s) - torch.lgamma(a).sum(dim=1, keepdim=True) + ((a - 1.0) * (torch.digamma(a) - torch.digamma(s))).sum(dim=1, keepdim=True)
-    return kl.squeeze(1).mean()
+    kl = kl.squeeze(1)
+    if not with_conf_weighting:
+        return kl.mean()
+    p_y = (alpha / (alpha.sum(dim=1, keepdim=True) + eps)).gather(1, target.unsqueeze(1)).squeeze(1)
+    w = ((1.0 - p_y).clamp(0.0, 1.0) ** gamma).reshape(alpha.shape[0], -1)[valid.reshape(alpha.shape[0], -1)].reshape(-1).detach()
+    return (kl * w).sum() / w.sum().clamp_min(1.0)
 
 
 def loss_complement_kl(alpha, target, ignore_index=0, gamma=2.0, tau=0.55, sigma=0.12, s_target=None, normalize=True, eps=1e-8, detach_uncert=True):

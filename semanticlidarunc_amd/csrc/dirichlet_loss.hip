@@ -7,6 +7,8 @@
 //   kind 4  KL_offClasses_to_uniform losses/regularizers.py:291-389       KL(Dir(alpha~) || Dir(1)), alpha~ = alpha with the true class set to 1
 //   kind 5  ComplementKLUniform      losses/dirichlet_losses.py:228-314   w(p_y) KL(p_off / (1 - p_y) || U) [/ ln(C-1)]; params gamma, tau, sigma,
 //                                                                         s_target (< 0: none), normalize, detach_uncert
+//   kind 7  KL_offClasses_to_uniform(with_conf_weighting=True)  :375-385     kind 4 times the detached weight (1 - p_y)^gamma, averaged over
+//                                                                         max(sum of the weights, 1); param gamma
 //   kind 6  WrongLowEvidence         losses/regularizers.py:218-289       gate * relu(ln a0 - ln(C + s_low + eps))^2 on wrong pixels, averaged over
 //                                                                         sum(gate) (second accumulator); params s_low, margin, soft_margin_k
 // One lane per pixel, class axis in registers, fp32 per pixel, fp64 sums: HBM-bound (4 C bytes in; backward 4 C in + 4 C out).
@@ -221,6 +223,15 @@ __global__ __launch_bounds__(256) void dirichlet_loss_kernel(const float* __rest
           sm1 += at[c] - 1.0f;
         }
       v = lgammaf(S) - slg + t2;
+      // kind 7: the confidence-weighted form (regularizers.py:375-385): w = clamp(1 - alpha_y / (alpha0 + eps), 0, 1)^gamma, detached;
+      // the mean then runs over sum(w) (second accumulator), the gradient is w * d KL / d alpha
+      float wconf = 1.0f;
+      if (kind == 7) {
+        const float om = fminf(fmaxf(1.0f - ay / (a0 + eps), 0.0f), 1.0f);
+        wconf = powf(om, prm.p[0]);
+        v *= wconf;
+        lsum2 += (double)wconf;
+      }
       if constexpr (BWD) {
         const float tS = trigamma_pos(S);
 #pragma unroll
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256) void dirichlet_loss_kernel(const float* __rest
           if (c < C) {
             // the true class is replaced by the constant 1; a clamped entry (alpha < eps) has zero gradient as well
             const bool live = c != y && a[c] >= eps;
-            dst[(size_t)c * HW] = live ? gs * ((at[c] - 1.0f) * trigamma_pos(at[c]) - tS * sm1) : 0.0f;
+            dst[(size_t)c * HW] = live ? gs * wconf * ((at[c] - 1.0f) * trigamma_pos(at[c]) - tS * sm1) : 0.0f;
           }
       }
     }
@@ -269,7 +280,7 @@ int launch(const float* alpha, const int64_t* labels, int B, int C, int HW, int 
 }
 
 bool fill_params(int kind, const float* params, int nparams, LossParams& prm) {
-  const int need = kind == 5 ? 6 : (kind == 6 ? 3 : (kind == 2 ? 1 : 0));
+  const int need = kind == 5 ? 6 : (kind == 6 ? 3 : ((kind == 2 || kind == 7) ? 1 : 0));
   if (nparams < need || (need && !params) || nparams > 6) return false;
   for (int i = 0; i < 6; ++i) prm.p[i] = i < nparams ? params[i] : 0.0f;
   if (kind == 5 && !(prm.p[2] > 0.0f)) return false;      // sigma
@@ -299,7 +310,7 @@ extern "C" int slu_dirichlet_loss_bwd(const float* alpha, const int64_t* labels,
 extern "C" int slu_dirichlet_loss_fwd_ex(const float* alpha, const int64_t* labels, int B, int C, int HW, int kind, const float* params, int nparams,
                                          float eps, int has_ignore, int64_t ignore_index, double* sums2, int64_t* count, slu_stream_t stream) {
   LossParams prm;
-  if (!alpha || !labels || !sums2 || !count || B <= 0 || C <= 0 || HW <= 0 || kind < 0 || kind > 6 || !fill_params(kind, params, nparams, prm)) return SLU_EINVAL;
+  if (!alpha || !labels || !sums2 || !count || B <= 0 || C <= 0 || HW <= 0 || kind < 0 || kind > 7 || !fill_params(kind, params, nparams, prm)) return SLU_EINVAL;
   if (C > 32) return SLU_EUNSUPPORTED;
   hipStream_t st = slu_stream(stream);
   if (hipMemsetAsync(sums2, 0, 2 * sizeof(double), st) != hipSuccess || hipMemsetAsync(count, 0, sizeof(int64_t), st) != hipSuccess) return SLU_ELAUNCH;
@@ -309,7 +320,7 @@ extern "C" int slu_dirichlet_loss_fwd_ex(const float* alpha, const int64_t* labe
 extern "C" int slu_dirichlet_loss_bwd_ex(const float* alpha, const int64_t* labels, int B, int C, int HW, int kind, const float* params, int nparams,
                                          float eps, int has_ignore, int64_t ignore_index, const float* gscale, float* grad_alpha, slu_stream_t stream) {
   LossParams prm;
-  if (!alpha || !labels || !gscale || !grad_alpha || B <= 0 || C <= 0 || HW <= 0 || kind < 0 || kind > 6 || !fill_params(kind, params, nparams, prm)) return SLU_EINVAL;
+  if (!alpha || !labels || !gscale || !grad_alpha || B <= 0 || C <= 0 || HW <= 0 || kind < 0 || kind > 7 || !fill_params(kind, params, nparams, prm)) return SLU_EINVAL;
   if (C > 32) return SLU_EUNSUPPORTED;
   return launch<true>(alpha, labels, B, C, HW, kind, prm, eps, has_ignore, ignore_index, nullptr, nullptr, nullptr, gscale, grad_alpha, slu_stream(stream));
 }

@@ -1,7 +1,8 @@
 """Drop-ins for two regularizers of the reference's default Dirichlet loss (``src/losses/regularizers.py``), each one fused HIP
 forward / backward pass (``csrc/dirichlet_loss.hip``):
 ``KL_offClasses_to_uniform`` (:291-389, the ``w_kl`` term): KL(Dir(alpha~) || Dir(1, ..., 1)) with the true class's alpha replaced
-by 1, mean over valid pixels (the confidence-weighted variant ``with_conf_weighting=True`` is not used by the Trainer and not mirrored);
+by 1, mean over valid pixels, or -- ``with_conf_weighting=True`` -- weighted per pixel by the detached (1 - p_y)^gamma and averaged over
+the sum of the weights;
 ``WrongLowEvidence`` (:218-289, the ``w_wle`` term): squared hinge on ln(alpha0) above ln(C + s_low) on confidently wrong pixels.
 ``LogitRegularizer`` / ``EvidenceReg(Band)`` come from the reference module in drop-in mode."""
 from __future__ import annotations
@@ -16,11 +17,11 @@ from .dirichlet_losses import _check_ignore, _DirichletLossExFn, _DirichletLossF
 class KL_offClasses_to_uniform(nn.Module):
     def __init__(self, ignore_index: Optional[int] = None, with_conf_weighting: bool = False, gamma: float = 1.0, eps: float = 1e-8):
         super().__init__()
-        if with_conf_weighting:
-            raise NotImplementedError("with_conf_weighting=True is not implemented on the HIP path")
-        self.ignore_index, self.eps, self.with_conf_weighting, self.gamma = _check_ignore(ignore_index), eps, False, gamma
+        self.ignore_index, self.eps, self.with_conf_weighting, self.gamma = _check_ignore(ignore_index), eps, bool(with_conf_weighting), gamma
 
     def forward(self, alpha, target):
+        if self.with_conf_weighting:      # per-pixel weight (1 - p_y)^gamma (detached), mean over max(sum of the weights, 1): :375-385
+            return _DirichletLossExFn.apply(alpha, target, "kl_off_uniform_weighted", (float(self.gamma),), self.eps, self.ignore_index, True)
         return _DirichletLossFn.apply(alpha, target, "kl_off_uniform", 0.0, self.eps, self.ignore_index)
 
 

@@ -868,7 +868,8 @@ def tversky_bwd(x: torch.Tensor, labels: torch.Tensor, model_act: str, ignore_in
 # ------------------------------------------------------------------------------------------------
 # per-pixel Dirichlet losses (losses/dirichlet_losses.py, losses/regularizers.py)
 # ------------------------------------------------------------------------------------------------
-DIRICHLET_LOSS_KINDS = {"nll_dircat": 0, "digamma_ce": 1, "brier": 2, "mse": 3, "kl_off_uniform": 4, "complement_kl": 5, "wrong_low_evidence": 6}
+DIRICHLET_LOSS_KINDS = {"nll_dircat": 0, "digamma_ce": 1, "brier": 2, "mse": 3, "kl_off_uniform": 4, "complement_kl": 5, "wrong_low_evidence": 6,
+                        "kl_off_uniform_weighted": 7}
 
 
 def _dirichlet_loss_args(alpha, labels):

@@ -196,28 +196,47 @@ def test_retain_graph_reentrant_and_eval_mode_grads(cuda):
 
 
 def test_full_size_training_step_against_oracle(cuda, train_precision):
-    """BASELINE configs[1] shape at batch 2 (64x2048): train-mode forward + fused SalsaNext loss + backward.
-    Loss terms are well conditioned (1e-3 relative); gradients are compared by direction (cosine >= 0.999)."""
+    """BASELINE configs[1]: batch 4 of 64x2048, train-mode forward (batch-statistics BatchNorm, 13 dropout sites with given multipliers) +
+    the SalsaNext loss (NLL + Lovasz, trainer.py:508-516) + backward.  Train-mode BatchNorm through ~50 layers amplifies fp32 round-off, so
+    every parameter gradient is judged PER TENSOR against an fp64 run of the oracle, with the fp32 oracle's own distance from it as the
+    yardstick: relative error of the HIP gradient <= 4 x the fp32 CPU oracle's + 1e-3 (same rule as the golden-size test above), or, for
+    the few tensors where the amplified round-off lands differently, <= 1.5 x the fp32 oracle's own worst tensor."""
     from oracle import losses as olosses
     from semanticlidarunc_amd.loss import salsanext_loss
     from semanticlidarunc_amd.testing import synthetic_scan
     model = seeded_model(SalsaNext).to(cuda).train()
-    x, y = synthetic_scan(2, 64, 2048, seed=21)
-    scales = osalsa.draw_dropout_scales(2, 0.2, torch.Generator().manual_seed(9))
+    x, y = synthetic_scan(4, 64, 2048, seed=21)
+    scales = osalsa.draw_dropout_scales(4, 0.2, torch.Generator().manual_seed(9))
     loss, nll, ls = salsanext_loss(model.forward_with_dropout_scales(x.to(cuda), scales), y.to(cuda), 1.0, 1.0, 0)
     loss.backward()
     pn = {k for k, _ in model.named_parameters()}
-    sd = {k: (v.detach().cpu().clone().requires_grad_(True) if k in pn else v.detach().cpu().clone()) for k, v in seeded_model(SalsaNext).state_dict().items()}
-    lo, nll_o, ls_o = olosses.salsanext_loss(osalsa.salsanext_forward(sd, x, scales, bn_train=True), y)
-    lo.backward()
-    assert abs(float(nll) - float(nll_o)) <= 1e-3 * float(nll_o) and abs(float(ls) - float(ls_o)) <= 1e-3
+    base = seeded_model(SalsaNext).state_dict()
+
+    def oracle(dtype):
+        sd = {k: (v.detach().clone().to(dtype).requires_grad_(True) if k in pn else v.detach().clone().to(dtype if v.is_floating_point() else v.dtype))
+              for k, v in base.items()}
+        sc = {k: v.to(dtype) for k, v in scales.items()}
+        lo, nll_o, ls_o = olosses.salsanext_loss(osalsa.salsanext_forward(sd, x.to(dtype), sc, bn_train=True), y)
+        lo.backward()
+        return sd, float(nll_o), float(ls_o)
+
+    sd32, nll32, ls32 = oracle(torch.float32)
+    sd64, nll64, ls64 = oracle(torch.float64)
+    assert abs(float(nll) - nll64) <= 2e-4 * nll64 + 4 * abs(nll32 - nll64) and abs(float(ls) - ls64) <= 2e-4 + 4 * abs(ls32 - ls64)
     params = dict(model.named_parameters())
-    for k in ("downCntx.conv2.weight", "resBlock1.conv3.weight", "resBlock4.conv5.weight", "upBlock1.conv1.weight", "upBlock4.conv4.weight",
-              "logits.weight", "resBlock2.bn2.weight", "upBlock3.bn1.bias"):
-        a, b = params[k].grad.cpu().flatten().double(), sd[k].grad.flatten().double()
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
-        assert cos >= 0.999, (k, cos)
-        assert abs(float(a.norm()) / float(b.norm()) - 1.0) <= 0.03, k
+    table = []
+    for k in sorted(pn):
+        truth = sd64[k].grad
+        table.append((_rel(params[k].grad.cpu().double(), truth), _rel(sd32[k].grad.double(), truth), k))
+    table.sort(reverse=True)
+    print("largest per-tensor gradient errors vs fp64 (HIP, fp32 CPU oracle):", [(k, round(a, 5), round(b, 5)) for a, b, k in table[:12]])
+    # Which tensor catches the amplified round-off differs between two fp32 evaluation orders (the CPU oracle itself is up to ~5 % off
+    # the fp64 run on some bottom-of-the-U-Net tensors and 0.5 % on their neighbours), so a tensor passes if it is within 4 x the fp32
+    # oracle's own error OR within 1.5 x the largest error that fp32 oracle shows on any tensor of this step (its noise floor).
+    floor = 1.5 * max(b for _, b, _ in table)
+    for e_hip, e_ref, k in table:
+        assert e_hip <= max(4.0 * e_ref + 1e-3, floor), (k, e_hip, e_ref, floor)
+    assert sum(1 for a, b, _ in table if a <= 4.0 * b + 1e-3) >= 0.9 * len(table)       # and most tensors meet the tight form
 
 
 def test_fused_bn_statistics(cuda):

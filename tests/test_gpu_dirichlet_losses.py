@@ -52,8 +52,6 @@ def test_against_reference_golden(cuda):
     w.backward()
     assert float(w.detach()) == 0.0 and float(right.grad.abs().max()) == 0.0
     with pytest.raises(NotImplementedError):
-        KL_offClasses_to_uniform(with_conf_weighting=True)
-    with pytest.raises(NotImplementedError):
         dl.NLLDirichletCategorical(ignore_index=(0, 1))
     with pytest.raises(RuntimeError):
         dl.BrierDirichlet()(alpha, lab.cpu())                                   # CPU tensor: no fallback
@@ -83,3 +81,29 @@ def test_full_size_against_oracle_and_reentrant_backward(cuda):
         assert torch.equal(g1, g2)
         assert abs(float(loss.detach()) - float(lo)) <= 1e-5 * max(1.0, abs(float(lo))), name
         assert float((g1.cpu() - ao.grad).abs().max()) <= 3e-5 * float(ao.grad.abs().max()), name
+
+
+def test_confidence_weighted_kl_against_reference_golden(cuda):
+    """KL_offClasses_to_uniform(with_conf_weighting=True) (regularizers.py:375-385): detached (1 - p_y)^gamma weights, mean over their sum."""
+    g = golden("kl_off_weighted_2x20x8x64")
+    lab, alpha = _t(g["labels"]).to(cuda), _t(g["alpha"])
+    for gamma in (1.0, 2.5):
+        a = alpha.to(cuda).requires_grad_(True)
+        loss = KL_offClasses_to_uniform(ignore_index=0, with_conf_weighting=True, gamma=gamma)(a, lab)
+        loss.backward()
+        want_l, want_g = float(g[f"loss:gamma{gamma}"]), _t(g[f"grad:gamma{gamma}"])
+        assert abs(float(loss.detach()) - want_l) <= 1e-5 * abs(want_l), (gamma, float(loss.detach()), want_l)
+        assert float((a.grad.cpu() - want_g).abs().max()) <= 3e-5 * float(want_g.abs().max()) + 1e-9
+        # re-entrant backward (grad_norm.py:52 probes with retain_graph)
+        a2 = alpha.to(cuda).requires_grad_(True)
+        l2 = KL_offClasses_to_uniform(ignore_index=0, with_conf_weighting=True, gamma=gamma)(a2, lab)
+        g1 = torch.autograd.grad(l2, a2, retain_graph=True)[0]
+        g2 = torch.autograd.grad(l2, a2)[0]
+        assert torch.equal(g1, g2)
+    # full size against the oracle
+    gen = torch.Generator().manual_seed(3)
+    big = 1.0 + torch.nn.functional.softplus(torch.randn(2, 20, 64, 2048, generator=gen) * 2.0) * torch.rand(2, 1, 64, 2048, generator=gen) * 30
+    bl = torch.randint(0, 20, (2, 64, 2048), generator=gen)
+    want = float(odir.loss_kl_off_uniform(big, bl, 0, with_conf_weighting=True, gamma=1.5))
+    got = float(KL_offClasses_to_uniform(ignore_index=0, with_conf_weighting=True, gamma=1.5)(big.to(cuda), bl.to(cuda)))
+    assert abs(got - want) <= 2e-5 * abs(want)

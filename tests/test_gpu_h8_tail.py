@@ -1,11 +1,12 @@
 """GPU: the fused tail of a SalsaNext block on the h8 path (2x2 dilated conv kept on chip + the 1x1 conv over the concatenation)
 against (a) the same two layers through the unfused h8 kernels -- same fp16 operands, same fp16 rounding of the intermediate, only the
-fp32 accumulation order of the 1x1 differs -- and (b) a plain torch fp32 evaluation on the fp16-rounded inputs.
-Bars: 2e-3 of the output scale vs the unfused path (one fp16 ulp of an O(1) output is 1e-3), 1e-2 vs fp32 torch."""
+fp32 accumulation order of the 1x1 differs -- and (b) the CPU oracle's fused-conv operator (oracle.salsanext.fused_conv, torch fp32 on
+the HOST) on the fp16-rounded inputs.  Bars: 2e-3 of the output scale vs the unfused path (one fp16 ulp of an O(1) output is 1e-3),
+3e-3 vs the fp32 CPU oracle (its output is not rounded to fp16)."""
 import pytest
 import torch
-import torch.nn.functional as F
 
+from oracle import salsanext as osalsa
 from semanticlidarunc_amd import h8
 
 pytestmark = pytest.mark.gpu
@@ -29,17 +30,16 @@ def _case(cuda, c, n, hh, ww, resid, seed, slope_a=0.01, slope_b=0.01, bn=True):
     h3 = h8.conv2d_h8([h8.H8Source(h2)], p2, c, c, 2, 2, 1, bias=ba, slope=slope_a, **kw(bna))
     unf = h8.from_h8(h8.conv2d_h8([h8.H8Source(h1), h8.H8Source(h2), h8.H8Source(h3)], p1, 3 * c, c, 1, 1, 0, bias=bb, slope=slope_b,
                                   resid=hr, **kw(bnb)), c)
-    # torch fp32 on the fp16-rounded operands
-    q = lambda t: t.half().float()
-    act = lambda t, s: t if s is None else F.leaky_relu(t, s)
-    aff = lambda t, pair: t if pair is None else t * pair[0].view(1, -1, 1, 1) + pair[1].view(1, -1, 1, 1)
-    a3 = q(aff(act(F.conv2d(q(a2), q(w2), ba, dilation=2, padding=1), slope_a), bna))
-    ref = aff(act(F.conv2d(torch.cat([q(a1), q(a2), a3], 1), q(w1), bb), slope_b), bnb)
-    if r is not None:
-        ref = ref + q(r)
+    # the CPU oracle (fp32, host) on the fp16-rounded operands; the intermediate a3 is rounded to fp16 where the device stores it
+    q = lambda t: t.half().float().cpu()
+    pair = lambda pr: (None, None) if pr is None else (pr[0].cpu(), pr[1].cpu())
+    a3 = osalsa.fused_conv([(q(a2), None, False)], q(w2), ba.cpu(), 1, 2, slope_a, *pair(bna)).half().float()
+    ref = osalsa.fused_conv([(q(a1), None, False), (q(a2), None, False), (a3, None, False)], q(w1), bb.cpu(), 0, 1, slope_b, *pair(bnb),
+                            resid=None if r is None else q(r))
+    fused, unf = fused.cpu(), unf.cpu()
     scale = float(ref.abs().max())
     assert float((fused - unf).abs().max()) <= 2e-3 * scale, (c, n, hh, ww, float((fused - unf).abs().max()), scale)
-    assert float((fused - ref).abs().max()) <= 1e-2 * scale, (c, n, hh, ww, float((fused - ref).abs().max()), scale)
+    assert float((fused - ref).abs().max()) <= 3e-3 * scale, (c, n, hh, ww, float((fused - ref).abs().max()), scale)
 
 
 @pytest.mark.parametrize("c", [32, 64, 128])

@@ -365,3 +365,13 @@ def test_fpn_opt_oracle_matches_reference_golden():
     torch.manual_seed(0)
     mine = SemanticNetworkWithFPN("resnet18", 2, 6, num_classes=20).state_dict()
     assert list(mine.keys()) == list(keys.keys()) and all(list(v.shape) == keys[k] for k, v in mine.items())
+
+
+def test_confidence_weighted_kl_oracle_matches_reference_golden():
+    from oracle import dirichlet as odir
+    g = golden("kl_off_weighted_2x20x8x64")
+    for gamma in (1.0, 2.5):
+        a = _t(g["alpha"]).clone().requires_grad_(True)
+        loss = odir.loss_kl_off_uniform(a, _t(g["labels"]), 0, with_conf_weighting=True, gamma=gamma)
+        loss.backward()
+        assert float(loss.detach()) == float(g[f"loss:gamma{gamma}"]) and float((a.grad - _t(g[f"grad:gamma{gamma}"])).abs().max()) == 0.0

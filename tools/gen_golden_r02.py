@@ -214,7 +214,29 @@ def gen_fpn_opt():
     print("  oracle.fpn_opt == reference baselines.Reichert.semanticFCN_opt (head wiring; backbone internals restated)")
 
 
-GENERATORS = {"ece": gen_ece, "kitti": gen_kitti, "fpn_opt": gen_fpn_opt}
+def gen_kl_weighted():
+    """KL_offClasses_to_uniform(with_conf_weighting=True) (losses/regularizers.py:375-385): value and gradient, two gammas."""
+    from losses import regularizers as ref_reg                           # reference
+    from oracle import dirichlet as odir
+    g = torch.Generator().manual_seed(808)
+    lab = torch.randint(0, 20, (2, 8, 64), generator=g)
+    lab[torch.rand(2, 8, 64, generator=g) < 0.12] = 0
+    alpha = 1.0 + torch.nn.functional.softplus(torch.randn(2, 20, 8, 64, generator=g) * 2.0) * torch.rand(2, 1, 8, 64, generator=g) * 30
+    out = {"labels": lab.numpy(), "alpha": alpha.numpy()}
+    for gamma in (1.0, 2.5):
+        ar = alpha.clone().requires_grad_(True)
+        lr = ref_reg.KL_offClasses_to_uniform(ignore_index=0, with_conf_weighting=True, gamma=gamma)(ar, lab)
+        lr.backward()
+        ao = alpha.clone().requires_grad_(True)
+        lo = odir.loss_kl_off_uniform(ao, lab, 0, with_conf_weighting=True, gamma=gamma)
+        lo.backward()
+        assert float((lr - lo).abs()) == 0.0 and float((ar.grad - ao.grad).abs().max()) == 0.0, gamma
+        out[f"loss:gamma{gamma}"], out[f"grad:gamma{gamma}"] = lr.detach().numpy(), ar.grad.numpy()
+        print(f"  KL_offClasses_to_uniform(with_conf_weighting, gamma={gamma}): reference = oracle = {float(lr):.6f}")
+    save("kl_off_weighted_2x20x8x64", **out)
+
+
+GENERATORS = {"ece": gen_ece, "kitti": gen_kitti, "fpn_opt": gen_fpn_opt, "kl_weighted": gen_kl_weighted}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(GENERATORS)):
