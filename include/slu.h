@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 20
+#define SLU_ABI_VERSION 21
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -229,6 +229,10 @@ int slu_dgrad_weight(const float* w, int cout, int cin, int ksize, float* wd, sl
 size_t slu_wgrad_packed_floats(int cout, int cin, int ksize);
 int slu_conv2d_wgrad(const float* da_t, const float* in_t, int N, int H, int W, int Cout, int Cin, int ksize, int dil, int pad,
                      float* dWp, float* dW, slu_stream_t stream);
+/* weight gradient of a 1x1 conv straight from the NCHW tensors (no channel-last copies): da [N,Cout,HW], the conv's sources as in
+ * slu_conv2d_fwd (plain tensors only: no PixelShuffle / multiplier / broadcast; every source but the last a multiple of 32 channels; HW a
+ * multiple of 32; 16-byte aligned bases) -> dW [Cout, sum of source channels].  SLU_EUNSUPPORTED otherwise (use slu_conv2d_wgrad). */
+int slu_conv1x1_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int HW, int Cout, float* dW, slu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * ResNet-FPN pieces (models/semanticFCN.py:145-153, 230-245, 266-354): data movement around the conv kernel.

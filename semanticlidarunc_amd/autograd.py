@@ -98,7 +98,10 @@ class ConvLayerFn(torch.autograd.Function):
         cin = weight.shape[1]
         dweight = None
         if need[1]:
-            dweight = ops.conv2d_wgrad(ops.nchw_to_nhwc(da), ops.gather_nhwc(srcs), n, h, w, cfg.cout, cin, cfg.ksize, cfg.dil, cfg.pad)
+            if cfg.ksize == 1:      # 1x1: straight from the NCHW tensors when the sources are plain and 32-aligned (all of SalsaNext's are)
+                dweight = ops.conv1x1_wgrad_nchw(da, srcs)
+            if dweight is None:
+                dweight = ops.conv2d_wgrad(ops.nchw_to_nhwc(da), ops.gather_nhwc(srcs), n, h, w, cfg.cout, cin, cfg.ksize, cfg.dil, cfg.pad)
         dsrc: List[Optional[torch.Tensor]] = [None] * nsrc
         if any(need[6:6 + nsrc]):
             # always the exact fp32 kernel: gradients reach 1e-8 and below, outside fp16's range (the split-fp16 products of

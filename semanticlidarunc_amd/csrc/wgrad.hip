@@ -186,6 +186,140 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(const float* __restric
     }
 }
 
+// 1x1 convs straight from the NCHW tensors (no channel-last copies of da / the inputs): lane (channel i, half k) loads FOUR consecutive
+// pixels of its channel with one 16-byte load -- pixels 8 u + 4 k .. + 3 of unit u -- and the four components feed four K-steps; the pixel
+// order inside the sum is permuted, which a sum does not care about, as long as A and B use the same permutation.  Sources of a concatenated
+// input are separate base pointers per 32-channel block (every concat of the network is 32-aligned).  MT x NT blocks per wave as above.
+struct W1Args {
+  const float* da;               // [N][Cout][HW]
+  const float* src[SLU_MAX_SRC]; // [N][Cs][HW]
+  int cs[SLU_MAX_SRC], cbeg[SLU_MAX_SRC];
+  int nsrc, N, HW, Cout, Cin;
+  float* dW;                     // [Cout][Cin], zeroed
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_nchw_kernel(const W1Args a) {
+  // unit = 32 pixels: lane (channel i, half k) owns pixels 32 u + 16 k .. + 15 of its channel = 64 contiguous bytes (4 x dwordx4), so the two
+  // halves of a channel cover one whole 128-byte line exactly once; 16 K-steps per unit, the next unit's loads in flight under them
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hh = lane >> 5, jj = lane & 31;
+  // 1-D grid, the tile index fastest: the workgroups that read the same pixels (other channel tiles) are dispatched together, so the
+  // re-reads of da / the inputs by the other tiles are cache hits, not HBM reads
+  const int ncob = (a.Cout + 31) / 32, ncib = (a.Cin + 31) / 32;
+  const int gy = (ncob + MT - 1) / MT, gz = (ncib + NT - 1) / NT;
+  const int tile = blockIdx.x % (gy * gz), bx = blockIdx.x / (gy * gz);
+  const int cob0 = (tile / gz) * MT, cib0 = (tile % gz) * NT;
+  const long long upi = a.HW / 32;                         // units per image
+  const long long nunits = (long long)a.N * upi;
+  const long long worker = (long long)bx * 4 + wave, nworkers = (long long)(gridDim.x / (gy * gz)) * 4;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const float* abase[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {   // lanes past the last channel read channel 0: their rows / columns of the product are never stored
+    const int co = (cob0 + i) * 32 + jj;
+    abase[i] = a.da + (size_t)((cob0 + i < ncob && co < a.Cout) ? co : 0) * a.HW + 16 * hh;
+  }
+  const float* bbase[NT];
+  long long bimg[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ci = (cib0 + j) * 32 + jj;
+    int s = 0;
+#pragma unroll
+    for (int t = 1; t < SLU_MAX_SRC; ++t)
+      if (t < a.nsrc && ci >= a.cbeg[t]) s = t;
+    const int cl = (cib0 + j < ncib && ci < a.Cin) ? ci - a.cbeg[s] : 0;
+    bbase[j] = a.src[s] + (size_t)cl * a.HW + 16 * hh;
+    bimg[j] = (long long)a.cs[s] * a.HW;
+  }
+  const long long aimg = (long long)a.Cout * a.HW;
+
+  // register budget (256 at two waves per SIMD): 16 (MT + NT) floats per buffered unit; the 2 x 2 tile buffers HALF units (Q = 2 loads per
+  // block) and alternates the two halves of one unit between the buffers, so a line is still consumed by one wave back to back
+  constexpr int Q = (MT + NT > 3) ? 2 : 4;
+  float4 av[2][MT][Q], bv[2][NT][Q];
+  auto load = [&](int buf, long long u, int part) {
+    const long long n = u / upi;
+    const long long p = (u - n * upi) * 32 + part * (4 * Q);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const float4* q = reinterpret_cast<const float4*>(abase[i] + n * aimg + p);
+#pragma unroll
+      for (int t = 0; t < Q; ++t) av[buf][i][t] = q[t];
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float4* q = reinterpret_cast<const float4*>(bbase[j] + n * bimg[j] + p);
+#pragma unroll
+      for (int t = 0; t < Q; ++t) bv[buf][j][t] = q[t];
+    }
+  };
+  auto mac = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < Q; ++t)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][i][t].x, bv[buf][j][t].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][i][t].y, bv[buf][j][t].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][i][t].z, bv[buf][j][t].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][i][t].w, bv[buf][j][t].w, acc[i][j], 0, 0, 0);
+        }
+  };
+  long long u = worker;
+  if (u < nunits) load(0, u, 0);
+  if constexpr (Q == 4) {
+    while (u < nunits) {                                    // two units per trip so the buffer index is a compile-time constant
+      const long long u1 = u + nworkers, u2 = u1 + nworkers;
+      if (u1 < nunits) load(1, u1, 0);
+      mac(0);
+      if (u1 >= nunits) break;
+      if (u2 < nunits) load(0, u2, 0);
+      mac(1);
+      u = u2;
+    }
+  } else {
+    while (u < nunits) {
+      const long long u1 = u + nworkers;
+      load(1, u, 1);
+      mac(0);
+      if (u1 < nunits) load(0, u1, 0);
+      mac(1);
+      u = u1;
+    }
+  }
+
+  __shared__ float s_red[4][16][64];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[i][j][r];
+      __syncthreads();
+      if (wave == ((i * NT + j) & 3)) {
+        const int ci = (cib0 + j) * 32 + jj;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = (s_red[0][r][lane] + s_red[1][r][lane]) + (s_red[2][r][lane] + s_red[3][r][lane]);
+          const int co = (cob0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (cob0 + i < ncob && cib0 + j < ncib && co < a.Cout && ci < a.Cin) atomicAdd(&a.dW[(size_t)co * a.Cin + ci], v);
+        }
+      }
+      __syncthreads();
+    }
+}
+
 __global__ void wgrad_unpack_kernel(const float* __restrict__ dWp, int Cout, int Cin, int T, int Cip, float* __restrict__ dW, size_t total) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int t = (int)(e % T);
@@ -243,7 +377,45 @@ int launch_wgrad1x1(const float* da_t, const float* in_t, long long npix, int Co
   return launch_wgrad1x1_t<1, 1>(da_t, in_t, npix, Cop, Cip, dWp, st);
 }
 
+template <int MT, int NT>
+int launch_w1_nchw_t(const W1Args& a, hipStream_t st) {
+  const int ncob = (a.Cout + 31) / 32, ncib = (a.Cin + 31) / 32;
+  const int gy = (ncob + MT - 1) / MT, gz = (ncib + NT - 1) / NT;
+  const long long nunits = (long long)a.N * (a.HW / 32);
+  const long long tiles = (long long)gy * gz;
+  long long gx = nunits / 32;                              // ~8 units per wave: the epilogue (LDS reduction + atomics) is paid per workgroup
+  const long long hi = 1024 / tiles > 1 ? 1024 / tiles : 1, lo = (256 + tiles - 1) / tiles;
+  if (gx > hi) gx = hi;
+  if (gx < lo) gx = lo;
+  if (gx * 4 > nunits) gx = (nunits + 3) / 4;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((wgrad1x1_nchw_kernel<MT, NT>), dim3((unsigned)(gx * tiles)), dim3(256), 0, st, a);
+  SLU_CHECK_LAUNCH();
+}
+
 }  // namespace
+
+extern "C" int slu_conv1x1_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int HW, int Cout, float* dW, slu_stream_t stream) {
+  if (!da || !src || !dW || nsrc < 1 || nsrc > SLU_MAX_SRC || N <= 0 || HW <= 0 || Cout <= 0) return SLU_EINVAL;
+  if (HW % 32 || ((uintptr_t)da & 15)) return SLU_EUNSUPPORTED;
+  W1Args a{};
+  int c = 0;
+  for (int s = 0; s < nsrc; ++s) {
+    if (!src[s].ptr || src[s].C <= 0) return SLU_EINVAL;
+    if (src[s].pixel_shuffle || src[s].scale || src[s].nbatch || src[s].cuse || ((uintptr_t)src[s].ptr & 15)) return SLU_EUNSUPPORTED;
+    if (s + 1 < nsrc && (src[s].C % 32)) return SLU_EUNSUPPORTED;          // a 32-channel block must not straddle two tensors
+    a.src[s] = src[s].ptr; a.cs[s] = src[s].C; a.cbeg[s] = c;
+    c += src[s].C;
+  }
+  a.da = da; a.nsrc = nsrc; a.N = N; a.HW = HW; a.Cout = Cout; a.Cin = c; a.dW = dW;
+  hipStream_t st = slu_stream(stream);
+  if (hipMemsetAsync(dW, 0, (size_t)Cout * c * sizeof(float), st) != hipSuccess) return SLU_ELAUNCH;
+  const int ncob = (Cout + 31) / 32, ncib = (c + 31) / 32;
+  if (ncob >= 2 && ncib >= 2) return launch_w1_nchw_t<2, 2>(a, st);
+  if (ncob >= 2) return launch_w1_nchw_t<2, 1>(a, st);
+  if (ncib >= 2) return launch_w1_nchw_t<1, 2>(a, st);
+  return launch_w1_nchw_t<1, 1>(a, st);
+}
 
 extern "C" size_t slu_wgrad_packed_floats(int cout, int cin, int ksize) {
   if (cout <= 0 || cin <= 0 || ksize <= 0) return 0;

@@ -92,6 +92,24 @@ def test_wgrad_and_dgrad_match_torch_autograd(cuda, fam, cin, cout):
     assert _rel(dx, x.grad) <= 1e-4
 
 
+@pytest.mark.parametrize("chans,cout,n,h,w", [((5,), 32, 2, 8, 40), ((32, 32, 32), 32, 3, 16, 64), ((64, 64, 72), 80, 2, 8, 28),
+                                               ((256, 256, 256), 256, 2, 4, 128), ((48,), 40, 1, 4, 8)])
+def test_wgrad_1x1_from_nchw(cuda, chans, cout, n, h, w):
+    """The 1x1 weight gradient read straight from NCHW da and the (concatenated) sources == autograd of F.conv2d on the CPU (1e-4 of the
+    gradient's scale: fp32 MFMA sums in another order, fp32 atomics); uncovered shapes return None (then the channel-last kernel runs)."""
+    g = torch.Generator().manual_seed(sum(chans) + cout)
+    xs = [torch.randn(n, c, h, w, generator=g) for c in chans]
+    wt = (torch.randn(cout, sum(chans), 1, 1, generator=g) / sum(chans) ** 0.5).requires_grad_(True)
+    da = torch.randn(n, cout, h, w, generator=g)
+    F.conv2d(torch.cat(xs, 1), wt).backward(da)
+    dw = ops.conv1x1_wgrad_nchw(da.to(cuda), [ConvSource(x.to(cuda)) for x in xs])
+    assert dw is not None and _rel(dw.cpu(), wt.grad) <= 1e-4
+    # not covered: H*W not a multiple of 32, an unaligned concat, PixelShuffle / multiplier sources
+    assert ops.conv1x1_wgrad_nchw(torch.zeros(1, 32, 3, 5, device=cuda), [ConvSource(torch.zeros(1, 32, 3, 5, device=cuda))]) is None
+    assert ops.conv1x1_wgrad_nchw(torch.zeros(1, 32, 4, 8, device=cuda), [ConvSource(torch.zeros(1, 5, 4, 8, device=cuda)), ConvSource(torch.zeros(1, 32, 4, 8, device=cuda))]) is None
+    assert ops.conv1x1_wgrad_nchw(torch.zeros(1, 32, 4, 8, device=cuda), [ConvSource(torch.zeros(1, 32, 4, 8, device=cuda), torch.ones(1, 32, device=cuda))]) is None
+
+
 def _layer_oracle(srcs, w, b, gamma, beta, resid, pad, dil, train, rm, rv):
     y = osalsa.fused_conv(srcs, w, b, pad, dil, 0.01)
     if train:

@@ -35,3 +35,31 @@ for cin, cout, k, dil, pad, h, w in SHAPES:
     tot += us
     print(f"{cin:4d}->{cout:3d} k{k}d{dil} {h:3d}x{w:4d}  {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s ({fl / us / 1e6 / 157.3 * 100:5.1f} % of fp32 MFMA peak)", flush=True)
 print(f"sum {tot:.0f} us")
+# the 1x1 layers straight from NCHW (slu_conv1x1_wgrad_nchw) against channel-last copies + the kernel above
+from semanticlidarunc_amd.ops import ConvSource  # noqa: E402
+for chans, cout, h, w in [((5,), 32, 64, 2048), ((64, 64, 64), 64, 64, 2048), ((32, 32, 32), 32, 64, 2048), ((128, 128, 128), 128, 32, 1024),
+                          ((256, 256, 256), 256, 16, 512), ((256, 256, 256), 256, 4, 128)]:
+    da = torch.randn(b, cout, h, w, device=dev)
+    xs = [ConvSource(torch.randn(b, c, h, w, device=dev)) for c in chans]
+    cin = sum(chans)
+
+    def old():
+        return ops.conv2d_wgrad(ops.nchw_to_nhwc(da), ops.gather_nhwc(xs), b, h, w, cout, cin, 1, 1, 0)
+
+    def new():
+        return ops.conv1x1_wgrad_nchw(da, xs)
+
+    res = []
+    for fn in (old, new):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 5 * 1e3)
+    gb = 4.0 * b * h * w * (cin + cout) / 1e3
+    print(f"1x1 {cin:4d}->{cout:3d} {h:3d}x{w:4d}  channel-last copies + kernel {res[0]:8.1f} us   from NCHW {res[1]:8.1f} us ({gb / res[1]:6.0f} GB/s of its inputs)", flush=True)
