@@ -16,11 +16,14 @@
 // -- the a3 image takes C * TH * 128 B = 64 KB in each.  W3RES: the 1x1 weights over a3 stay resident in LDS (C <= 64); otherwise
 // they stream through the chunk pipeline as NKS more (weights-only) chunks, for which the LDS has no room at C = 128.
 #include "slu_common.h"
+#include <cstdlib>
+#include <utility>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -40,6 +43,7 @@ struct TailArgs {
   uint2* out;
   int N, H, W, G;              // G = C / 8 channel blocks
   int tiles_x, tiles_y;
+  int dbg;                     // development: 1 = ring DMAs copy the zero record (no input traffic), 2 = no MFMA work
 };
 
 template <int MB, int WM, int WN, int RPW, bool W3RES>
@@ -289,6 +293,357 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void tail_h8_kernel(const TailArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Version 2 (C = 32, 64: one wave owns ALL channels of its pixels).  The kernel above keeps ~21 KB of DMA in flight per CU -- against
+// the ~43 KB that 5.5 TB/s x ~2 us of loaded HBM latency asks of each of the 256 CUs -- because 64 KB of LDS hold the a3 tile and
+// every chunk re-fetches its weight fragments.  Here
+//   * a3 never leaves the registers: the 32x32 accumulator layout gives lane (pixel jj, half hh) the channels 32 i + 8 q + 4 hh + e;
+//     the 1x1 over a3 runs its K-steps in THAT channel order (k = 2 i + p: channels 32 i + 16 p + {4 hh + e, 8 + 4 hh + e}), so the
+//     converted accumulators ARE the B operands, and the matching weight fragments are permuted once per workgroup when they are
+//     made resident -- no LDS image, no barrier, no ds_read for a3;
+//   * every weight (2x2, 1x1 over a1 | a2 | a3) is resident in LDS for the life of the persistent workgroup;
+//   * the freed LDS is a ring of D input chunks, D - 1 of them in flight (C = 64: 3 x 21 KB; C = 32: 2 x 38 KB), with COUNTED vmcnt
+//     waits: every wave issues the same number of VM operations at every position of a tile (surplus DMA slots copy the zero record
+//     to a trash block; beyond the last tile the whole chunk does), so "chunk c has landed" is vmcnt(younger(c)), a constant;
+//   * a1 chunks carry no halo (the 1x1 needs none); the residual is loaded into registers one half-tile ahead of the epilogue.
+// VM operations a wave of tail2_h8_kernel issues after the DMA of chunk c and before the top of position c (positions are cyclic over
+// tiles): position s issues  DMA(chunk s + P) [, the NRES residual loads if s == PR] ... [, the NST stores after position NCH - 1]
+template <int NKS, int NIB, int NI1, int P, int PR, int NRES, int NST>
+constexpr int tail2_younger(int c) {
+  constexpr int NCH = 2 * NKS;
+  int n = 0;
+  const int s0 = ((c - P) % NCH + NCH) % NCH;
+  if (s0 == PR) n += NRES;
+  if (s0 == NCH - 1) n += NST;
+  for (int d = 1; d < P; ++d) {
+    const int s = (s0 + d) % NCH;
+    n += ((s + P) % NCH < NKS) ? NIB : NI1;
+    if (s == PR) n += NRES;
+    if (s == NCH - 1) n += NST;
+  }
+  return n;
+}
+
+template <class F, int... Cs>
+__device__ __forceinline__ void tail2_static_for(F&& f, std::integer_sequence<int, Cs...>) {
+  (f(std::integral_constant<int, Cs>{}), ...);
+}
+
+// ring DMAs a wave issues after its residual loads (top of position PR) and before the epilogue
+template <int NKS, int NIB, int NI1, int P, int PR>
+constexpr int tail2_res_wait() {
+  constexpr int NCH = 2 * NKS;
+  int n = 0;
+  for (int s = PR + 1; s < NCH; ++s) n += ((s + P) % NCH < NKS) ? NIB : NI1;
+  return n;
+}
+
+template <int MB, int RPW, int D, bool HASRES>
+__global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
+  constexpr int NWAVE = 8, T = 4, PAD = 1, DIL = 2, P = D - 1;
+  constexpr int C = 32 * MB, NKS = 2 * MB, NCH = 2 * NKS;
+  constexpr int TW = 64, TH = NWAVE * RPW, NB = 2 * RPW;
+  constexpr int LW = TW + 2 * PAD, LH = TH + 2 * PAD, REC = LH * LW;
+  constexpr int NBLK_B = (2 * REC + 63) / 64, NIB = (NBLK_B + NWAVE - 1) / NWAVE;     // a2 chunk: 64-record blocks, DMA slots per wave
+  constexpr int NI1 = 2 * TH / NWAVE;                                                  // a1 chunk: 2 groups x TH rows of 64 records
+  constexpr int BUFREC = NBLK_B * 64;
+  constexpr int NRES = HASRES ? MB * NB * 4 : 0, NST = MB * NB * 4;
+  constexpr int PR = NKS;                                                              // position whose top issues the residual loads
+  static_assert(P >= 1 && P < NCH && NCH % 1 == 0, "ring depth");
+
+  // the epilogue constants live in a STATIC array: a distinct object from the DMA'd dynamic LDS, so the compiler does not guard their
+  // reads with s_waitcnt vmcnt(0) ("may alias an LDS-DMA write in flight"), which would drain the ring twice per tile
+  __shared__ __attribute__((aligned(16))) float s_epi[6 * C];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* s_w2 = reinterpret_cast<uint4*>(smem);                     // [MB][NKS][4][64]
+  uint4* s_w1 = s_w2 + MB * NKS * T * 64;                           // [MB][3 NKS][64], the a3 third K-permuted
+  uint4* s_ring = s_w1 + MB * 3 * NKS * 64;                         // [D][BUFREC]
+  uint4* s_trash = s_ring + D * BUFREC;                             // [64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave;
+  const int hh = lane >> 5, jj = lane & 31;
+  const size_t HW = (size_t)a.H * a.W;
+
+  int t_beg, t_end, t_step;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
+    t_step = nwg;
+    t_beg = w;
+    t_end = w < nt ? w + (int)((nt - w + nwg - 1) / nwg) * nwg : w;
+  }
+  if (t_beg >= t_end) return;
+
+  if (tid < C) {
+    s_epi[tid] = a.biasA ? a.biasA[tid] : 0.0f;
+    s_epi[C + tid] = a.bnA_a ? a.bnA_a[tid] : 1.0f;
+    s_epi[2 * C + tid] = a.bnA_a ? a.bnA_b[tid] : 0.0f;
+    s_epi[3 * C + tid] = a.biasB ? a.biasB[tid] : 0.0f;
+    s_epi[4 * C + tid] = a.bnB_a ? a.bnB_a[tid] : 1.0f;
+    s_epi[5 * C + tid] = a.bnB_a ? a.bnB_b[tid] : 0.0f;
+  }
+  for (int blk = wave; blk < MB * NKS * T; blk += NWAVE) SLU_GLDS16_T(a.w2 + (size_t)blk * 64 + lane, s_w2 + blk * 64);
+  for (int blk = wave; blk < MB * 3 * NKS; blk += NWAVE) {
+    const int k = blk % (3 * NKS);
+    if (k < 2 * NKS) {
+      SLU_GLDS16_T(a.w1 + (size_t)blk * 64 + lane, s_w1 + blk * 64);
+    } else {   // K-step over a3 in accumulator order: elements 4 hh .. 4 hh + 3 of the standard fragments of lanes (row, 0) and (row, 1)
+      const uint2* w = reinterpret_cast<const uint2*>(a.w1 + (size_t)blk * 64);
+      const uint2 lo = w[jj * 2 + hh], hi = w[(32 + jj) * 2 + hh];
+      s_w1[blk * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+  }
+
+  struct TilePos { int x0, y0, n; };
+  auto decode = [&](int t) {
+    TilePos p;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    p.x0 = tx * TW;
+    p.y0 = (t % a.tiles_y) * TH;
+    p.n = t / a.tiles_y;
+    return p;
+  };
+  int pc_rc[NIB], pc_off[NIB];
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    const int e = (i * NWAVE + wave) * 64 + lane;
+    const int g2 = e / REC, rem = e - g2 * REC, r = rem / LW, c = rem - r * LW;
+    pc_rc[i] = r | (c << 8) | ((g2 & 1) << 16) | ((e < 2 * REC ? 1 : 0) << 17);
+    pc_off[i] = r * a.W + c;
+  }
+  // chunk c of a tile into ring slot `slot`: c < NKS: K-step c of a2 with its halo; else K-step c - NKS of a1, no halo.  `valid` false
+  // (no such tile): the same DMA instructions, every lane copying the zero record
+  auto stage = [&](const TilePos& tp, int c, int slot, bool valid) {
+    uint4* db = s_ring + slot * BUFREC;
+    const uintptr_t zero = reinterpret_cast<uintptr_t>(&g_zero_rec_t);
+    if (c < NKS) {
+      const uintptr_t base0 = reinterpret_cast<uintptr_t>(a.a2) +
+                              16 * ((long long)(((size_t)tp.n * a.G + 2 * c) * HW) + (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD));
+      const uintptr_t base1 = base0 + 16 * (long long)HW;
+#pragma unroll
+      for (int i = 0; i < NIB; ++i) {
+        const int blk = i * NWAVE + wave;
+        const int rc = pc_rc[i];
+        const int gy = tp.y0 - PAD + (rc & 255), gx = tp.x0 - PAD + ((rc >> 8) & 255);
+        const bool ok = valid && (rc >> 17) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const uintptr_t p = ok ? (((rc >> 16) & 1) ? base1 : base0) + 16 * (long long)pc_off[i] : zero;
+        SLU_GLDS16_T(reinterpret_cast<const uint4*>(p), (NBLK_B % NWAVE == 0 || blk < NBLK_B) ? db + blk * 64 : s_trash);
+      }
+    } else {
+      const int q = c - NKS;
+#pragma unroll
+      for (int i = 0; i < NI1; ++i) {
+        const int blk = i * NWAVE + wave, g2 = blk / TH, row = blk - g2 * TH;
+        const int gy = tp.y0 + row, gx = tp.x0 + lane;
+        const bool ok = valid && gy < a.H && gx < a.W;
+        const uintptr_t p = ok ? reinterpret_cast<uintptr_t>(a.a1) + 16 * ((long long)(((size_t)tp.n * a.G + 2 * q + g2) * HW) + (long long)gy * a.W + gx) : zero;
+        SLU_GLDS16_T(reinterpret_cast<const uint4*>(p), db + blk * 64);
+      }
+    }
+    asm volatile("" ::: "memory");
+  };
+  const int bbase2 = hh * REC + (wn * RPW) * LW + jj;      // a2 chunk (halo) ; a1 chunk (no halo):
+  const int bbase1 = hh * (TH * 64) + (wn * RPW) * 64 + jj;
+  TilePos cur = decode(t_beg), nxt = cur;
+  bool has_next = t_beg + t_step < t_end;
+  if (has_next) nxt = decode(t_beg + t_step);
+#pragma unroll
+  for (int c = 0; c < P; ++c) stage(cur, c, c, true);
+  int rslot = 0, wslot = P % D;
+  bool first = true;
+  const float2v slA = {a.slopeA, a.slopeA}, slB = {a.slopeB, a.slopeB};
+  // NATIVE vector loads: the waitcnt pass guards an LDS read that carries no TBAA tag (a HIP float4 / uint4 struct copied by value)
+  // with s_waitcnt vmcnt(0) while any LDS-DMA is in flight -- which would drain the ring twice per tile; tagged reads are left to the
+  // counted waits of this kernel
+  const f32x4v* se4p = reinterpret_cast<const f32x4v*>(s_epi) + hh;
+  auto se4 = [&](int k) { return se4p[k]; };
+
+  for (int tile = t_beg; tile < t_end; tile += t_step) {
+    f32x16 acc3[MB][NB], acco[MB][NB];
+    unsigned long long res[HASRES ? MB : 1][HASRES ? NB : 1][4];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc3[i][b][r] = 0.0f; acco[i][b][r] = 0.0f; }
+
+    auto position = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      constexpr int YOUNG = tail2_younger<NKS, NIB, NI1, P, PR, NRES, NST>(c);
+      static_assert(YOUNG <= 63, "vmcnt is a 6-bit counter");
+      if (first && c < P) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first tile's prologue (and the resident weights)
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      {
+        constexpr int cn = (c + P) % NCH;
+        if (c + P < NCH) stage(cur, cn, wslot, !(a.dbg & 1));
+        else stage(nxt, cn, wslot, has_next && !(a.dbg & 1));
+        wslot = wslot + 1 == D ? 0 : wslot + 1;
+      }
+      if constexpr (HASRES && c == PR) {
+        // the residual of this tile, as untracked loads (inline asm): the compiler would wait for a tracked load with vmcnt(0) -- every
+        // ring DMA issued since -- where vmcnt(RESWAIT) is enough; lanes outside the image read record 0 of the image and store to trash
+        const unsigned long long rbase = reinterpret_cast<unsigned long long>(a.resid) + 16ull * ((size_t)cur.n * a.G * HW);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
+            const bool ok = gy < a.H && gx < a.W;
+            const unsigned voff0 = ok ? (unsigned)((((size_t)(i * 4) * HW + (size_t)gy * a.W + gx) << 4) + 8 * hh) : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned voff = voff0 + (unsigned)(q * HW * 16);
+              asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(res[i][b][q]) : "v"(voff), "s"(rbase) : "memory");
+            }
+          }
+      }
+      const uint4* ring = s_ring + rslot * BUFREC;
+      rslot = rslot + 1 == D ? 0 : rslot + 1;
+      if (a.dbg & 2) {
+      } else if constexpr (c < NKS) {
+        const uint4* sb = ring + bbase2;
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+          const int dy = (tap >> 1) * DIL, dx = (tap & 1) * DIL;
+          half8 af[MB];
+#pragma unroll
+          for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, s_w2[((i * NKS + c) * T + tap) * 64 + lane]);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const half8 bf = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc3[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acc3[i][b], 0, 0, 0);
+          }
+        }
+        half8 af[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, s_w1[(i * 3 * NKS + NKS + c) * 64 + lane]);      // cat order (a1, a2, a3)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const half8 bf = __builtin_bit_cast(half8, sb[((b >> 1) + PAD) * LW + (b & 1) * 32 + PAD]);
+#pragma unroll
+          for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acco[i][b], 0, 0, 0);
+        }
+      } else {
+        const uint4* sb = ring + bbase1;
+        half8 af[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, s_w1[(i * 3 * NKS + (c - NKS)) * 64 + lane]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const half8 bf = __builtin_bit_cast(half8, sb[(b >> 1) * 64 + (b & 1) * 32]);
+#pragma unroll
+          for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acco[i][b], 0, 0, 0);
+        }
+      }
+      if constexpr (c == NKS - 1) {
+        // epilogue A in registers: a3 = bnA(act(acc3 + biasA)) rounded to fp16 (the rounding the unfused path applies when it stores a3)
+        // is the B operand of K-step k = 2 i + p of the 1x1 over a3 (channel order of the accumulator, see the head of this kernel)
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            half8 wf[MB];
+#pragma unroll
+            for (int io = 0; io < MB; ++io) wf[io] = __builtin_bit_cast(half8, s_w1[(io * 3 * NKS + 2 * NKS + 2 * i + p) * 64 + lane]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              unsigned u[4];
+#pragma unroll
+              for (int q2 = 0; q2 < 2; ++q2) {
+                const int q = 2 * p + q2;
+                const int c4 = (i * 32 + 8 * q) / 4;
+                const f32x4v bi = se4(c4), ba = se4(C / 4 + c4), bb = se4(2 * C / 4 + c4);
+                float2v t0 = {acc3[i][b][4 * q], acc3[i][b][4 * q + 1]}, t1 = {acc3[i][b][4 * q + 2], acc3[i][b][4 * q + 3]};
+                t0 += float2v{bi.x, bi.y};
+                t1 += float2v{bi.z, bi.w};
+                t0 = __builtin_elementwise_max(t0, t0 * slA);
+                t1 = __builtin_elementwise_max(t1, t1 * slA);
+                t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
+                t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
+                u[2 * q2] = __builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v));
+                u[2 * q2 + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v));
+              }
+              const half8 bf = __builtin_bit_cast(half8, make_uint4(u[0], u[1], u[2], u[3]));
+#pragma unroll
+              for (int io = 0; io < MB; ++io) acco[io][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[io], bf, acco[io][b], 0, 0, 0);
+            }
+          }
+      }
+    };
+    tail2_static_for(position, std::make_integer_sequence<int, NCH>{});
+    first = false;
+
+    // ---- epilogue B: NST stores per lane (counted in younger()) ----
+    if constexpr (HASRES) {
+      static_assert(MB * NB == 4, "the wait below names 16 registers");
+      constexpr int RESWAIT = tail2_res_wait<NKS, NIB, NI1, P, PR>();
+      asm volatile("s_waitcnt vmcnt(%16)"
+                   : "+v"(res[0][0][0]), "+v"(res[0][0][1]), "+v"(res[0][0][2]), "+v"(res[0][0][3]),
+                     "+v"(res[(1 / NB) % MB][1 % NB][0]), "+v"(res[(1 / NB) % MB][1 % NB][1]), "+v"(res[(1 / NB) % MB][1 % NB][2]), "+v"(res[(1 / NB) % MB][1 % NB][3]),
+                     "+v"(res[(2 / NB) % MB][2 % NB][0]), "+v"(res[(2 / NB) % MB][2 % NB][1]), "+v"(res[(2 / NB) % MB][2 % NB][2]), "+v"(res[(2 / NB) % MB][2 % NB][3]),
+                     "+v"(res[(3 / NB) % MB][3 % NB][0]), "+v"(res[(3 / NB) % MB][3 % NB][1]), "+v"(res[(3 / NB) % MB][3 % NB][2]), "+v"(res[(3 / NB) % MB][3 % NB][3])
+                   : "n"(RESWAIT));
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
+        const bool ok = gy < a.H && gx < a.W;
+        const size_t idx0 = ok ? ((((size_t)cur.n * a.G + i * 4) * HW + (size_t)gy * a.W + gx) << 1) + hh : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c4 = (i * 32 + 8 * q) / 4;
+          const f32x4v bi = se4(3 * C / 4 + c4), ba = se4(4 * C / 4 + c4), bb = se4(5 * C / 4 + c4);
+          float2v t0 = {acco[i][b][4 * q], acco[i][b][4 * q + 1]}, t1 = {acco[i][b][4 * q + 2], acco[i][b][4 * q + 3]};
+          t0 += float2v{bi.x, bi.y};
+          t1 += float2v{bi.z, bi.w};
+          t0 = __builtin_elementwise_max(t0, t0 * slB);
+          t1 = __builtin_elementwise_max(t1, t1 * slB);
+          t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
+          t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
+          if constexpr (HASRES) {
+            t0 += __builtin_convertvector(__builtin_bit_cast(half2v, (unsigned)res[i][b][q]), float2v);
+            t1 += __builtin_convertvector(__builtin_bit_cast(half2v, (unsigned)(res[i][b][q] >> 32)), float2v);
+          }
+          *(ok ? a.out + idx0 + (size_t)q * HW * 2 : reinterpret_cast<uint2*>(&g_trash_rec_t)) =
+              make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v)), __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v)));
+        }
+      }
+    asm volatile("" ::: "memory");
+    cur = nxt;
+    has_next = tile + 2 * t_step < t_end;
+    if (has_next) nxt = decode(tile + 2 * t_step);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-record DMAs issued for the tile after the last: LDS must not be released under them
+}
+
+template <int MB, int RPW, int D, bool HASRES>
+int launch_tail2(TailArgs& a, hipStream_t st) {
+  constexpr int TH = 8 * RPW, C = 32 * MB, NKS = 2 * MB;
+  constexpr size_t nblk_b = (size_t)(2 * (TH + 2) * 66 + 63) / 64;
+  constexpr size_t lds = ((size_t)MB * NKS * 4 * 64 + (size_t)MB * 3 * NKS * 64 + (size_t)D * nblk_b * 64 + 64) * 16;      // + 6 C floats static
+  static_assert(lds + 6 * C * 4 <= 160 * 1024, "ring does not fit in LDS");
+  a.tiles_x = (a.W + 63) / 64;
+  a.tiles_y = (a.H + TH - 1) / TH;
+  const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
+  if (nt <= 0 || nt > 0x7fffffffLL) return SLU_EUNSUPPORTED;
+  long long gx = 256;
+  if (gx > nt) gx = nt;
+  auto kern = tail2_h8_kernel<MB, RPW, D, HASRES>;
+  static SluLdsGrant grant;
+  if (slu_grant_dynamic_lds(reinterpret_cast<const void*>(kern), lds, grant) != SLU_OK) return SLU_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds, st, a);
+  SLU_CHECK_LAUNCH();
+}
+
 template <int MB, int WM, int WN, int RPW, bool W3RES>
 int launch_tail(TailArgs& a, hipStream_t st) {
   constexpr int TH = WN * RPW, MBLK = MB * WM, C = 32 * MBLK, NKS = 2 * MBLK;
@@ -332,7 +687,12 @@ extern "C" int slu_conv_tail_h8_fwd(const slu_conv_tail_h8_desc* d, slu_stream_t
   a.resid = reinterpret_cast<const uint2*>(d->resid);
   a.out = reinterpret_cast<uint2*>(d->out);
   a.N = d->N; a.H = d->H; a.W = d->W; a.G = d->C / 8;
+  static const int dbg = [] { const char* e = getenv("SLU_TAIL_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   hipStream_t st = slu_stream(stream);
+  static const bool v1 = [] { const char* e = getenv("SLU_TAIL_V1"); return e && e[0] == '1'; }();     // A/B switch: the round-1 kernel
+  if (!v1 && d->C == 32) return a.resid ? launch_tail2<1, 2, 3, true>(a, st) : launch_tail2<1, 2, 3, false>(a, st);
+  if (!v1 && d->C == 64) return a.resid ? launch_tail2<2, 1, 4, true>(a, st) : launch_tail2<2, 1, 4, false>(a, st);
   if (d->C == 32) return launch_tail<1, 1, 8, 2, true>(a, st);
   if (d->C == 64) return launch_tail<2, 1, 8, 1, true>(a, st);
   return launch_tail<2, 2, 4, 1, false>(a, st);
