@@ -24,6 +24,7 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -296,63 +297,55 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void tail_h8_kernel(const TailArgs
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Version 2 (C = 32, 64: one wave owns ALL channels of its pixels).  The kernel above keeps ~21 KB of DMA in flight per CU -- against
 // the ~43 KB that 5.5 TB/s x ~2 us of loaded HBM latency asks of each of the 256 CUs -- because 64 KB of LDS hold the a3 tile and
-// every chunk re-fetches its weight fragments.  Here
+// every chunk re-fetches its weight fragments; its epilogue loads the residual one record at a time.  Here
 //   * a3 never leaves the registers: the 32x32 accumulator layout gives lane (pixel jj, half hh) the channels 32 i + 8 q + 4 hh + e;
 //     the 1x1 over a3 runs its K-steps in THAT channel order (k = 2 i + p: channels 32 i + 16 p + {4 hh + e, 8 + 4 hh + e}), so the
 //     converted accumulators ARE the B operands, and the matching weight fragments are permuted once per workgroup when they are
 //     made resident -- no LDS image, no barrier, no ds_read for a3;
+//   * a1 and the residual never touch LDS either: the 1x1 conv is pixel-local, so lane (jj, hh) loads exactly the h8 records that are
+//     its B operands (a1) / its epilogue addends (resid) straight into registers, one half-tile ahead of their use;
 //   * every weight (2x2, 1x1 over a1 | a2 | a3) is resident in LDS for the life of the persistent workgroup;
-//   * the freed LDS is a ring of D input chunks, D - 1 of them in flight (C = 64: 3 x 21 KB; C = 32: 2 x 38 KB), with COUNTED vmcnt
-//     waits: every wave issues the same number of VM operations at every position of a tile (surplus DMA slots copy the zero record
-//     to a trash block; beyond the last tile the whole chunk does), so "chunk c has landed" is vmcnt(younger(c)), a constant;
-//   * a1 chunks carry no halo (the 1x1 needs none); the residual is loaded into registers one half-tile ahead of the epilogue.
-// VM operations a wave of tail2_h8_kernel issues after the DMA of chunk c and before the top of position c (positions are cyclic over
-// tiles): position s issues  DMA(chunk s + P) [, the NRES residual loads if s == PR] ... [, the NST stores after position NCH - 1]
-template <int NKS, int NIB, int NI1, int P, int PR, int NRES, int NST>
-constexpr int tail2_younger(int c) {
-  constexpr int NCH = 2 * NKS;
-  int n = 0;
-  const int s0 = ((c - P) % NCH + NCH) % NCH;
-  if (s0 == PR) n += NRES;
-  if (s0 == NCH - 1) n += NST;
-  for (int d = 1; d < P; ++d) {
-    const int s = (s0 + d) % NCH;
-    n += ((s + P) % NCH < NKS) ? NIB : NI1;
-    if (s == PR) n += NRES;
-    if (s == NCH - 1) n += NST;
-  }
+//   * the freed LDS is a ring of D a2 chunks (with halo), D - 1 of them in flight (C = 64: 3 x 21 KB; C = 32: 2 x 38 KB);
+//   * every wait is a COUNTED vmcnt: each wave issues the same VM operations at every position of every tile (surplus DMA slots copy
+//     the zero record to a trash block; beyond the last tile whole chunks do), the register loads are inline asm the compiler does not
+//     track (it would wait for them with vmcnt(0), draining the ring), so "chunk c has landed" is vmcnt(younger(c)), a constant.
+// One tile = NKS positions; position s, in program order:
+//   wait(chunk s) | barrier | DMA(chunk s + P) | s == 0: a1 loads | s == NKS / 2: wait + consume a1, then residual loads |
+//   chunk s: 4 dilated taps -> acc3, centre tap -> acc_out | s == NKS - 1: a3 in registers -> acc_out ;  after the last: epilogue, stores
+template <int NKS, int NIB, int P, int NA1, int NRES, int NST>
+constexpr int tail2_ops_after_dma(int s) {       // VM operations position s issues after its DMA
+  return (s == 0 ? NA1 : 0) + (s == NKS / 2 ? NRES : 0) + (s == NKS - 1 ? NST : 0);
+}
+template <int NKS, int NIB, int P, int NA1, int NRES, int NST>
+constexpr int tail2_younger(int c) {             // ... issued after the DMA of chunk c and before the top of position c (cyclic over tiles)
+  const int s0 = ((c - P) % NKS + NKS) % NKS;
+  int n = tail2_ops_after_dma<NKS, NIB, P, NA1, NRES, NST>(s0);
+  for (int d = 1; d < P; ++d) n += NIB + tail2_ops_after_dma<NKS, NIB, P, NA1, NRES, NST>((s0 + d) % NKS);
   return n;
 }
-
 template <class F, int... Cs>
 __device__ __forceinline__ void tail2_static_for(F&& f, std::integer_sequence<int, Cs...>) {
   (f(std::integral_constant<int, Cs>{}), ...);
 }
 
-// ring DMAs a wave issues after its residual loads (top of position PR) and before the epilogue
-template <int NKS, int NIB, int NI1, int P, int PR>
-constexpr int tail2_res_wait() {
-  constexpr int NCH = 2 * NKS;
-  int n = 0;
-  for (int s = PR + 1; s < NCH; ++s) n += ((s + P) % NCH < NKS) ? NIB : NI1;
-  return n;
-}
-
 template <int MB, int RPW, int D, bool HASRES>
 __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
   constexpr int NWAVE = 8, T = 4, PAD = 1, DIL = 2, P = D - 1;
-  constexpr int C = 32 * MB, NKS = 2 * MB, NCH = 2 * NKS;
+  constexpr int C = 32 * MB, NKS = 2 * MB;
   constexpr int TW = 64, TH = NWAVE * RPW, NB = 2 * RPW;
   constexpr int LW = TW + 2 * PAD, LH = TH + 2 * PAD, REC = LH * LW;
   constexpr int NBLK_B = (2 * REC + 63) / 64, NIB = (NBLK_B + NWAVE - 1) / NWAVE;     // a2 chunk: 64-record blocks, DMA slots per wave
-  constexpr int NI1 = 2 * TH / NWAVE;                                                  // a1 chunk: 2 groups x TH rows of 64 records
   constexpr int BUFREC = NBLK_B * 64;
-  constexpr int NRES = HASRES ? MB * NB * 4 : 0, NST = MB * NB * 4;
-  constexpr int PR = NKS;                                                              // position whose top issues the residual loads
-  static_assert(P >= 1 && P < NCH && NCH % 1 == 0, "ring depth");
+  constexpr int NA1 = NKS * NB, NRES = HASRES ? MB * NB * 2 : 0, NST = MB * NB * 2;      // whole 16-byte records per lane, see epilogue B
+  constexpr int CA = NKS / 2;                                                          // position that consumes a1 and loads the residual
+  constexpr int A1WAIT = CA * NIB;                                                     // DMAs issued after the a1 loads, before their use
+  constexpr int RESWAIT = (NKS - 1 - CA) * NIB;                                        // ... after the residual loads, before the epilogue
+  static_assert(P >= 1 && P <= NKS, "ring depth");
+  static_assert(NA1 == 8 && MB * NB == 4, "the counted waits below name their registers");
 
-  // the epilogue constants live in a STATIC array: a distinct object from the DMA'd dynamic LDS, so the compiler does not guard their
-  // reads with s_waitcnt vmcnt(0) ("may alias an LDS-DMA write in flight"), which would drain the ring twice per tile
+  // NATIVE vector loads of the epilogue constants: the waitcnt pass guards an LDS read that carries no TBAA tag (a HIP float4 / uint4
+  // struct copied by value) with s_waitcnt vmcnt(0) while any LDS-DMA is in flight -- which would drain the ring; tagged reads are left
+  // to the counted waits of this kernel
   __shared__ __attribute__((aligned(16))) float s_epi[6 * C];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* s_w2 = reinterpret_cast<uint4*>(smem);                     // [MB][NKS][4][64]
@@ -360,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
   uint4* s_ring = s_w1 + MB * 3 * NKS * 64;                         // [D][BUFREC]
   uint4* s_trash = s_ring + D * BUFREC;                             // [64]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave;
   const int hh = lane >> 5, jj = lane & 31;
   const size_t HW = (size_t)a.H * a.W;
 
@@ -411,68 +404,62 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
     const int e = (i * NWAVE + wave) * 64 + lane;
     const int g2 = e / REC, rem = e - g2 * REC, r = rem / LW, c = rem - r * LW;
     pc_rc[i] = r | (c << 8) | ((g2 & 1) << 16) | ((e < 2 * REC ? 1 : 0) << 17);
-    pc_off[i] = r * a.W + c;
+    pc_off[i] = (r * a.W + c) * 16;
   }
-  // chunk c of a tile into ring slot `slot`: c < NKS: K-step c of a2 with its halo; else K-step c - NKS of a1, no halo.  `valid` false
-  // (no such tile): the same DMA instructions, every lane copying the zero record
+  // K-step c of a2 with its halo into ring slot `slot`.  `valid` false (no such tile): the same DMA instructions, every lane copying the
+  // zero record
   auto stage = [&](const TilePos& tp, int c, int slot, bool valid) {
     uint4* db = s_ring + slot * BUFREC;
     const uintptr_t zero = reinterpret_cast<uintptr_t>(&g_zero_rec_t);
-    if (c < NKS) {
-      const uintptr_t base0 = reinterpret_cast<uintptr_t>(a.a2) +
-                              16 * ((long long)(((size_t)tp.n * a.G + 2 * c) * HW) + (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD));
-      const uintptr_t base1 = base0 + 16 * (long long)HW;
+    const uintptr_t base0 = reinterpret_cast<uintptr_t>(a.a2) +
+                            16 * ((long long)(((size_t)tp.n * a.G + 2 * c) * HW) + (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD));
+    const uintptr_t base1 = base0 + 16 * (long long)HW;
 #pragma unroll
-      for (int i = 0; i < NIB; ++i) {
-        const int blk = i * NWAVE + wave;
-        const int rc = pc_rc[i];
-        const int gy = tp.y0 - PAD + (rc & 255), gx = tp.x0 - PAD + ((rc >> 8) & 255);
-        const bool ok = valid && (rc >> 17) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        const uintptr_t p = ok ? (((rc >> 16) & 1) ? base1 : base0) + 16 * (long long)pc_off[i] : zero;
-        SLU_GLDS16_T(reinterpret_cast<const uint4*>(p), (NBLK_B % NWAVE == 0 || blk < NBLK_B) ? db + blk * 64 : s_trash);
-      }
-    } else {
-      const int q = c - NKS;
-#pragma unroll
-      for (int i = 0; i < NI1; ++i) {
-        const int blk = i * NWAVE + wave, g2 = blk / TH, row = blk - g2 * TH;
-        const int gy = tp.y0 + row, gx = tp.x0 + lane;
-        const bool ok = valid && gy < a.H && gx < a.W;
-        const uintptr_t p = ok ? reinterpret_cast<uintptr_t>(a.a1) + 16 * ((long long)(((size_t)tp.n * a.G + 2 * q + g2) * HW) + (long long)gy * a.W + gx) : zero;
-        SLU_GLDS16_T(reinterpret_cast<const uint4*>(p), db + blk * 64);
-      }
+    for (int i = 0; i < NIB; ++i) {
+      const int blk = i * NWAVE + wave;
+      const int rc = pc_rc[i];
+      const int gy = tp.y0 - PAD + (rc & 255), gx = tp.x0 - PAD + ((rc >> 8) & 255);
+      const bool ok = valid && (rc >> 17) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      const uintptr_t p = ok ? (((rc >> 16) & 1) ? base1 : base0) + (long long)pc_off[i] : zero;
+      SLU_GLDS16_T(reinterpret_cast<const uint4*>(p), (NBLK_B % NWAVE == 0 || blk < NBLK_B) ? db + blk * 64 : s_trash);
     }
     asm volatile("" ::: "memory");
   };
-  const int bbase2 = hh * REC + (wn * RPW) * LW + jj;      // a2 chunk (halo) ; a1 chunk (no halo):
-  const int bbase1 = hh * (TH * 64) + (wn * RPW) * 64 + jj;
+
+  const int bbase2 = hh * REC + (wn * RPW) * LW + jj;
   TilePos cur = decode(t_beg), nxt = cur;
   bool has_next = t_beg + t_step < t_end;
   if (has_next) nxt = decode(t_beg + t_step);
 #pragma unroll
-  for (int c = 0; c < P; ++c) stage(cur, c, c, true);
+  for (int c = 0; c < P; ++c) stage(cur, c, c, !(a.dbg & 1));
   int rslot = 0, wslot = P % D;
   bool first = true;
   const float2v slA = {a.slopeA, a.slopeA}, slB = {a.slopeB, a.slopeB};
-  // NATIVE vector loads: the waitcnt pass guards an LDS read that carries no TBAA tag (a HIP float4 / uint4 struct copied by value)
-  // with s_waitcnt vmcnt(0) while any LDS-DMA is in flight -- which would drain the ring twice per tile; tagged reads are left to the
-  // counted waits of this kernel
   const f32x4v* se4p = reinterpret_cast<const f32x4v*>(s_epi) + hh;
   auto se4 = [&](int k) { return se4p[k]; };
 
   for (int tile = t_beg; tile < t_end; tile += t_step) {
     f32x16 acc3[MB][NB], acco[MB][NB];
-    unsigned long long res[HASRES ? MB : 1][HASRES ? NB : 1][4];
+    u32x4v a1r[NKS][NB];
+    u32x4v res[HASRES ? MB : 1][HASRES ? NB : 1][2];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc3[i][b][r] = 0.0f; acco[i][b][r] = 0.0f; }
+    // this lane's records inside image cur.n: channel block 0 (+ hh), pixel of accumulator block b; lanes outside the image read record 0
+    unsigned voff[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
+      voff[b] = (gy < a.H && gx < a.W) ? (unsigned)(((size_t)gy * a.W + gx) << 4) : 0u;
+    }
+    const unsigned long long img16 = 16ull * ((size_t)cur.n * a.G * HW);
 
     auto position = [&](auto cc) {
       constexpr int c = decltype(cc)::value;
-      constexpr int YOUNG = tail2_younger<NKS, NIB, NI1, P, PR, NRES, NST>(c);
+      constexpr int YOUNG = tail2_younger<NKS, NIB, P, NA1, NRES, NST>(c);
       static_assert(YOUNG <= 63, "vmcnt is a 6-bit counter");
       if (first && c < P) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first tile's prologue (and the resident weights)
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");
@@ -480,66 +467,78 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       {
-        constexpr int cn = (c + P) % NCH;
-        if (c + P < NCH) stage(cur, cn, wslot, !(a.dbg & 1));
+        constexpr int cn = (c + P) % NKS;
+        if (c + P < NKS) stage(cur, cn, wslot, !(a.dbg & 1));
         else stage(nxt, cn, wslot, has_next && !(a.dbg & 1));
         wslot = wslot + 1 == D ? 0 : wslot + 1;
       }
-      if constexpr (HASRES && c == PR) {
-        // the residual of this tile, as untracked loads (inline asm): the compiler would wait for a tracked load with vmcnt(0) -- every
-        // ring DMA issued since -- where vmcnt(RESWAIT) is enough; lanes outside the image read record 0 of the image and store to trash
-        const unsigned long long rbase = reinterpret_cast<unsigned long long>(a.resid) + 16ull * ((size_t)cur.n * a.G * HW);
+      if constexpr (c == 0) {       // a1: K-step k of pixel block b = the record of channel block 2 k + hh
+        const unsigned long long base = reinterpret_cast<unsigned long long>(a.a1) + img16;
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
+        for (int k = 0; k < NKS; ++k)
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
-            const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
-            const bool ok = gy < a.H && gx < a.W;
-            const unsigned voff0 = ok ? (unsigned)((((size_t)(i * 4) * HW + (size_t)gy * a.W + gx) << 4) + 8 * hh) : 0u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const unsigned voff = voff0 + (unsigned)(q * HW * 16);
-              asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(res[i][b][q]) : "v"(voff), "s"(rbase) : "memory");
-            }
+            const unsigned vo = voff[b] + (unsigned)((2 * k + hh) * HW * 16);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(a1r[k][b]) : "v"(vo), "s"(base) : "memory");
           }
       }
-      const uint4* ring = s_ring + rslot * BUFREC;
-      rslot = rslot + 1 == D ? 0 : rslot + 1;
-      if (a.dbg & 2) {
-      } else if constexpr (c < NKS) {
-        const uint4* sb = ring + bbase2;
+      if constexpr (c == CA) {
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(a1r[0][0]), "+v"(a1r[0][1]), "+v"(a1r[(2 / NB) % NKS][2 % NB]), "+v"(a1r[(3 / NB) % NKS][3 % NB]),
+                       "+v"(a1r[(4 / NB) % NKS][4 % NB]), "+v"(a1r[(5 / NB) % NKS][5 % NB]), "+v"(a1r[(6 / NB) % NKS][6 % NB]), "+v"(a1r[(7 / NB) % NKS][7 % NB])
+                     : "n"(A1WAIT));
+        if (!(a.dbg & 2)) {
 #pragma unroll
-        for (int tap = 0; tap < T; ++tap) {
-          const int dy = (tap >> 1) * DIL, dx = (tap & 1) * DIL;
-          half8 af[MB];
+          for (int k = 0; k < NKS; ++k) {
+            half8 af[MB];
 #pragma unroll
-          for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, s_w2[((i * NKS + c) * T + tap) * 64 + lane]);
+            for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, s_w1[(i * 3 * NKS + k) * 64 + lane]);      // cat order (a1, a2, a3)
 #pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const half8 bf = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int i = 0; i < MB; ++i) acc3[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acc3[i][b], 0, 0, 0);
+              for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], __builtin_bit_cast(half8, a1r[k][b]), acco[i][b], 0, 0, 0);
           }
         }
-        half8 af[MB];
+        if constexpr (HASRES) {       // whole records: lane (jj, hh) loads record 2 pr + hh of channel block i (un-swapped in epilogue B)
+          const unsigned long long base = reinterpret_cast<unsigned long long>(a.resid) + img16;
 #pragma unroll
-        for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, s_w1[(i * 3 * NKS + NKS + c) * 64 + lane]);      // cat order (a1, a2, a3)
+          for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const half8 bf = __builtin_bit_cast(half8, sb[((b >> 1) + PAD) * LW + (b & 1) * 32 + PAD]);
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-          for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acco[i][b], 0, 0, 0);
+              for (int pr = 0; pr < 2; ++pr) {
+                const unsigned vo = voff[b] + (unsigned)((i * 4 + 2 * pr + hh) * HW * 16);
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(res[i][b][pr]) : "v"(vo), "s"(base) : "memory");
+              }
         }
-      } else {
-        const uint4* sb = ring + bbase1;
-        half8 af[MB];
+      }
+      const uint4* sb = s_ring + rslot * BUFREC + bbase2;
+      rslot = rslot + 1 == D ? 0 : rslot + 1;
+      if (!(a.dbg & 2)) {
+        // 5 steps (4 dilated taps -> acc3, the centre tap = the 1x1 over a2 -> acc_out), fragments double-buffered: the reads of step
+        // s + 1 are issued before the MFMAs of step s, in THIS order (the compiler's own schedule is read, wait, MFMA, read, wait, ...)
+        half8 fa[2][MB], fb[2][NB];
+        auto rd = [&](int st, int buf) {
+          const int dy = st < T ? (st >> 1) * DIL : PAD, dx = st < T ? (st & 1) * DIL : PAD;
 #pragma unroll
-        for (int i = 0; i < MB; ++i) af[i] = __builtin_bit_cast(half8, s_w1[(i * 3 * NKS + (c - NKS)) * 64 + lane]);
+          for (int i = 0; i < MB; ++i)
+            fa[buf][i] = __builtin_bit_cast(half8, st < T ? s_w2[((i * NKS + c) * T + st) * 64 + lane] : s_w1[(i * 3 * NKS + NKS + c) * 64 + lane]);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const half8 bf = __builtin_bit_cast(half8, sb[(b >> 1) * 64 + (b & 1) * 32]);
+          for (int b = 0; b < NB; ++b) fb[buf][b] = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+        };
+        rd(0, 0);
 #pragma unroll
-          for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf, acco[i][b], 0, 0, 0);
+        for (int st = 0; st <= T; ++st) {
+          if (st < T) rd(st + 1, (st + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+              if (st < T) acc3[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st & 1][i], fb[st & 1][b], acc3[i][b], 0, 0, 0);
+              else acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st & 1][i], fb[st & 1][b], acco[i][b], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       if constexpr (c == NKS - 1) {
@@ -577,18 +576,17 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
           }
       }
     };
-    tail2_static_for(position, std::make_integer_sequence<int, NCH>{});
+    tail2_static_for(position, std::make_integer_sequence<int, NKS>{});
     first = false;
 
-    // ---- epilogue B: NST stores per lane (counted in younger()) ----
+    // ---- epilogue B: NST stores per lane (counted in tail2_younger).  The accumulator gives lane (jj, hh) HALF of each 16-byte record
+    // (channels 8 q + 4 hh + 0..3 of pixel jj); v_permlane32_swap trades halves between lanes jj and jj + 32 so that lane (jj, hh) owns
+    // the WHOLE record 2 pr + hh: one dwordx4 per lane, each half-wave a contiguous 512 bytes -- half the memory instructions and no
+    // half-written 64-byte lines on the way to L2.  The residual comes in the same way and is un-swapped first. ----
     if constexpr (HASRES) {
-      static_assert(MB * NB == 4, "the wait below names 16 registers");
-      constexpr int RESWAIT = tail2_res_wait<NKS, NIB, NI1, P, PR>();
-      asm volatile("s_waitcnt vmcnt(%16)"
-                   : "+v"(res[0][0][0]), "+v"(res[0][0][1]), "+v"(res[0][0][2]), "+v"(res[0][0][3]),
-                     "+v"(res[(1 / NB) % MB][1 % NB][0]), "+v"(res[(1 / NB) % MB][1 % NB][1]), "+v"(res[(1 / NB) % MB][1 % NB][2]), "+v"(res[(1 / NB) % MB][1 % NB][3]),
-                     "+v"(res[(2 / NB) % MB][2 % NB][0]), "+v"(res[(2 / NB) % MB][2 % NB][1]), "+v"(res[(2 / NB) % MB][2 % NB][2]), "+v"(res[(2 / NB) % MB][2 % NB][3]),
-                     "+v"(res[(3 / NB) % MB][3 % NB][0]), "+v"(res[(3 / NB) % MB][3 % NB][1]), "+v"(res[(3 / NB) % MB][3 % NB][2]), "+v"(res[(3 / NB) % MB][3 % NB][3])
+      asm volatile("s_waitcnt vmcnt(%8)"
+                   : "+v"(res[0][0][0]), "+v"(res[0][0][1]), "+v"(res[(1 / NB) % MB][1 % NB][0]), "+v"(res[(1 / NB) % MB][1 % NB][1]),
+                     "+v"(res[(2 / NB) % MB][2 % NB][0]), "+v"(res[(2 / NB) % MB][2 % NB][1]), "+v"(res[(3 / NB) % MB][3 % NB][0]), "+v"(res[(3 / NB) % MB][3 % NB][1])
                    : "n"(RESWAIT));
     }
 #pragma unroll
@@ -597,24 +595,39 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
       for (int b = 0; b < NB; ++b) {
         const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
         const bool ok = gy < a.H && gx < a.W;
-        const size_t idx0 = ok ? ((((size_t)cur.n * a.G + i * 4) * HW + (size_t)gy * a.W + gx) << 1) + hh : 0;
+        const size_t idx0 = ok ? ((size_t)cur.n * a.G + i * 4 + hh) * HW + (size_t)gy * a.W + gx : 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c4 = (i * 32 + 8 * q) / 4;
-          const f32x4v bi = se4(3 * C / 4 + c4), ba = se4(4 * C / 4 + c4), bb = se4(5 * C / 4 + c4);
-          float2v t0 = {acco[i][b][4 * q], acco[i][b][4 * q + 1]}, t1 = {acco[i][b][4 * q + 2], acco[i][b][4 * q + 3]};
-          t0 += float2v{bi.x, bi.y};
-          t1 += float2v{bi.z, bi.w};
-          t0 = __builtin_elementwise_max(t0, t0 * slB);
-          t1 = __builtin_elementwise_max(t1, t1 * slB);
-          t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
-          t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
+        for (int pr = 0; pr < 2; ++pr) {
+          unsigned rw[4] = {0u, 0u, 0u, 0u};       // residual words: [0..1] for q = 2 pr, [2..3] for q = 2 pr + 1
           if constexpr (HASRES) {
-            t0 += __builtin_convertvector(__builtin_bit_cast(half2v, (unsigned)res[i][b][q]), float2v);
-            t1 += __builtin_convertvector(__builtin_bit_cast(half2v, (unsigned)(res[i][b][q] >> 32)), float2v);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(res[i][b][pr].x, res[i][b][pr].z, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(res[i][b][pr].y, res[i][b][pr].w, false, false);
+            rw[0] = s0[0]; rw[1] = s1[0]; rw[2] = s0[1]; rw[3] = s1[1];
           }
-          *(ok ? a.out + idx0 + (size_t)q * HW * 2 : reinterpret_cast<uint2*>(&g_trash_rec_t)) =
-              make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v)), __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v)));
+          unsigned hw[4];
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2) {
+            const int q = 2 * pr + q2;
+            const int c4 = (i * 32 + 8 * q) / 4;
+            const f32x4v bi = se4(3 * C / 4 + c4), ba = se4(4 * C / 4 + c4), bb = se4(5 * C / 4 + c4);
+            float2v t0 = {acco[i][b][4 * q], acco[i][b][4 * q + 1]}, t1 = {acco[i][b][4 * q + 2], acco[i][b][4 * q + 3]};
+            t0 += float2v{bi.x, bi.y};
+            t1 += float2v{bi.z, bi.w};
+            t0 = __builtin_elementwise_max(t0, t0 * slB);
+            t1 = __builtin_elementwise_max(t1, t1 * slB);
+            t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
+            t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
+            if constexpr (HASRES) {
+              t0 += __builtin_convertvector(__builtin_bit_cast(half2v, rw[2 * q2]), float2v);
+              t1 += __builtin_convertvector(__builtin_bit_cast(half2v, rw[2 * q2 + 1]), float2v);
+            }
+            hw[2 * q2] = __builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v));
+            hw[2 * q2 + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v));
+          }
+          const auto s0 = __builtin_amdgcn_permlane32_swap(hw[0], hw[2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(hw[1], hw[3], false, false);
+          uint4* dst = ok ? reinterpret_cast<uint4*>(a.out) + idx0 + (size_t)(2 * pr) * HW : &g_trash_rec_t;
+          *dst = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
       }
     asm volatile("" ::: "memory");
