@@ -14,6 +14,8 @@
 //   plus layout / pooling / pixel-shuffle helpers at the end of the file.
 #include <stdio.h>
 #include "slu_common.h"
+#include <cstdlib>
+#include <utility>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -912,6 +914,277 @@ int launch_h8_k(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
   SLU_CHECK_LAUNCH();
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// 3x3 convs of the full-resolution layers with 32 / 64 input and output channels, ONE plain source: the deep-ring form.
+// conv_h8_kernel keeps one 16-channel chunk (~21-43 KB) of DMA in flight per CU while it multiplies the previous one; at
+// 5.5 TB/s x ~2 us of loaded latency a CU needs ~43 KB in flight ALL the time, and these layers have too little MFMA work
+// per chunk to cover one round trip.  Here (the structure of tail2_h8_kernel, conv_tail_h8.hip):
+//   * all weights resident in LDS for the life of the persistent workgroup (<= 72 KB);
+//   * the rest of the LDS is a ring of D input chunks (16 channels with halo), D - 1 of them in flight;
+//   * one wave owns ALL output channels of its pixels (MB blocks) and RPW rows; fragments double-buffered in source order;
+//   * counted vmcnt waits: every wave issues the same VM operations at every position of every tile (surplus DMA slots
+//     copy the zero record to a trash block, beyond the last tile whole chunks do);
+//   * whole 16-byte records per lane on the way out (v_permlane32_swap between lanes jj and jj + 32).
+// One tile = NKS positions: wait(chunk s) | barrier | DMA(chunk s + P) | 9 taps of chunk s ; after the last: epilogue, NST stores.
+// -----------------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct RingArgs {
+  const uint4 *x, *x1;         // h8 [N][G0][H][W] (+ a second plain source [N][G1][H][W], G0 + G1 = 2 NKS, G0 even: the concatenation)
+  int G0, G1;
+  const uint4* wpack;          // [MB][NKS][9][64]
+  const float *bias, *bn_a, *bn_b;
+  float slope;                 // 1 = no activation
+  uint4* out;                  // h8 [N][4 MB][H][W]
+  int N, H, W, tiles_x, tiles_y;
+};
+
+template <int NKS, int NIB, int P, int NST>
+constexpr int ring3_younger(int c) {             // VM operations issued after the DMA of chunk c and before the top of position c
+  const int s0 = ((c - P) % NKS + NKS) % NKS;
+  int n = s0 == NKS - 1 ? NST : 0;
+  for (int d = 1; d < P; ++d) n += NIB + ((s0 + d) % NKS == NKS - 1 ? NST : 0);
+  return n;
+}
+template <class F, int... Cs>
+__device__ __forceinline__ void ring3_static_for(F&& f, std::integer_sequence<int, Cs...>) {
+  (f(std::integral_constant<int, Cs>{}), ...);
+}
+
+template <int DIL, int MB, int NKS, int RPW, int D>
+__global__ __launch_bounds__(512, 2) void ring3_h8_kernel(const RingArgs a) {
+  constexpr int NWAVE = 8, KS = 3, T = 9, PAD = DIL, P = D - 1;
+  constexpr int C = 32 * MB, GO = 4 * MB;
+  constexpr int TW = 64, TH = NWAVE * RPW, NB = 2 * RPW;
+  constexpr int LW = TW + 2 * PAD, LH = TH + 2 * PAD, REC = LH * LW;
+  constexpr int NBLK_B = (2 * REC + 63) / 64, NIB = (NBLK_B + NWAVE - 1) / NWAVE;
+  constexpr int BUFREC = NBLK_B * 64;
+  constexpr int NST = MB * NB * 2;
+  static_assert(P >= 1 && P <= NKS, "ring depth");
+
+  // static array + native vector loads: see tail2_h8_kernel (reads without a TBAA tag are guarded with vmcnt(0) by the compiler)
+  __shared__ __attribute__((aligned(16))) float s_epi[3 * C];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* s_w = reinterpret_cast<uint4*>(smem);                      // [MB][NKS][9][64]
+  uint4* s_ring = s_w + MB * NKS * T * 64;                          // [D][BUFREC]
+  uint4* s_trash = s_ring + D * BUFREC;                             // [64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave;
+  const int hh = lane >> 5, jj = lane & 31;
+  const size_t HW = (size_t)a.H * a.W;
+
+  int t_beg, t_end, t_step;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
+    t_step = nwg;
+    t_beg = w;
+    t_end = w < nt ? w + (int)((nt - w + nwg - 1) / nwg) * nwg : w;
+  }
+  if (t_beg >= t_end) return;
+
+  if (tid < C) {
+    s_epi[tid] = a.bias ? a.bias[tid] : 0.0f;
+    s_epi[C + tid] = a.bn_a ? a.bn_a[tid] : 1.0f;
+    s_epi[2 * C + tid] = a.bn_a ? a.bn_b[tid] : 0.0f;
+  }
+  for (int blk = wave; blk < MB * NKS * T; blk += NWAVE) SLU_GLDS16(a.wpack + (size_t)blk * 64 + lane, s_w + blk * 64);
+
+  struct TilePos { int x0, y0, n; };
+  auto decode = [&](int t) {
+    TilePos p;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    p.x0 = tx * TW;
+    p.y0 = (t % a.tiles_y) * TH;
+    p.n = t / a.tiles_y;
+    return p;
+  };
+  int pc_rc[NIB], pc_off[NIB];
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    const int e = (i * NWAVE + wave) * 64 + lane;
+    const int g2 = e / REC, rem = e - g2 * REC, r = rem / LW, c = rem - r * LW;
+    pc_rc[i] = r | (c << 8) | ((g2 & 1) << 16) | ((e < 2 * REC ? 1 : 0) << 17);
+    pc_off[i] = (r * a.W + c) * 16;
+  }
+  auto stage = [&](const TilePos& tp, int c, int slot, bool valid) {
+    uint4* db = s_ring + slot * BUFREC;
+    const uintptr_t zero = reinterpret_cast<uintptr_t>(&g_zero_rec);
+    const bool second = 2 * c >= a.G0;                  // a K-step never straddles the two sources (G0 is even)
+    const uint4* src = second ? a.x1 : a.x;
+    const int gs = second ? a.G1 : a.G0, g = second ? 2 * c - a.G0 : 2 * c;
+    const uintptr_t base0 = reinterpret_cast<uintptr_t>(src) +
+                            16 * ((long long)(((size_t)tp.n * gs + g) * HW) + (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD));
+    const uintptr_t base1 = base0 + 16 * (long long)HW;
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int blk = i * NWAVE + wave;
+      const int rc = pc_rc[i];
+      const int gy = tp.y0 - PAD + (rc & 255), gx = tp.x0 - PAD + ((rc >> 8) & 255);
+      const bool ok = valid && (rc >> 17) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      const uintptr_t p = ok ? (((rc >> 16) & 1) ? base1 : base0) + (long long)pc_off[i] : zero;
+      SLU_GLDS16(reinterpret_cast<const uint4*>(p), (NBLK_B % NWAVE == 0 || blk < NBLK_B) ? db + blk * 64 : s_trash);
+    }
+    asm volatile("" ::: "memory");
+  };
+
+  const int bbase = hh * REC + (wn * RPW) * LW + jj;
+  TilePos cur = decode(t_beg), nxt = cur;
+  bool has_next = t_beg + t_step < t_end;
+  if (has_next) nxt = decode(t_beg + t_step);
+#pragma unroll
+  for (int c = 0; c < P; ++c) stage(cur, c, c, true);
+  int rslot = 0, wslot = P % D;
+  bool first = true;
+  const float2v sl = {a.slope, a.slope};
+  const f32x4v* se4p = reinterpret_cast<const f32x4v*>(s_epi) + hh;
+
+  for (int tile = t_beg; tile < t_end; tile += t_step) {
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
+
+    auto position = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      constexpr int YOUNG = ring3_younger<NKS, NIB, P, NST>(c);
+      static_assert(YOUNG <= 63, "vmcnt is a 6-bit counter");
+      if (first && c < P) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first tile's prologue (and the resident weights)
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      {
+        constexpr int cn = (c + P) % NKS;
+        if (c + P < NKS) stage(cur, cn, wslot, true);
+        else stage(nxt, cn, wslot, has_next);
+        wslot = wslot + 1 == D ? 0 : wslot + 1;
+      }
+      const uint4* sb = s_ring + rslot * BUFREC + bbase;
+      rslot = rslot + 1 == D ? 0 : rslot + 1;
+      half8 fa[2][MB], fb[2][NB];
+      auto rd = [&](int tap, int buf) {
+        const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) fa[buf][i] = __builtin_bit_cast(half8, s_w[((i * NKS + c) * T + tap) * 64 + lane]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) fb[buf][b] = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+      };
+      rd(0, 0);
+#pragma unroll
+      for (int tap = 0; tap < T; ++tap) {
+        if (tap + 1 < T) rd(tap + 1, (tap + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tap & 1][i], fb[tap & 1][b], acc[i][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    ring3_static_for(position, std::make_integer_sequence<int, NKS>{});
+    first = false;
+
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
+        const bool ok = gy < a.H && gx < a.W;
+        const size_t idx0 = ok ? ((size_t)cur.n * GO + i * 4 + hh) * HW + (size_t)gy * a.W + gx : 0;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          unsigned hw[4];
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2) {
+            const int q = 2 * pr + q2;
+            const int c4 = (i * 32 + 8 * q) / 4;
+            const f32x4v bi = se4p[c4], ba = se4p[C / 4 + c4], bb = se4p[2 * C / 4 + c4];
+            float2v t0 = {acc[i][b][4 * q], acc[i][b][4 * q + 1]}, t1 = {acc[i][b][4 * q + 2], acc[i][b][4 * q + 3]};
+            t0 += float2v{bi.x, bi.y};
+            t1 += float2v{bi.z, bi.w};
+            t0 = __builtin_elementwise_max(t0, t0 * sl);
+            t1 = __builtin_elementwise_max(t1, t1 * sl);
+            t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
+            t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
+            hw[2 * q2] = __builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v));
+            hw[2 * q2 + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v));
+          }
+          const auto s0 = __builtin_amdgcn_permlane32_swap(hw[0], hw[2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(hw[1], hw[3], false, false);
+          uint4* dst = ok ? a.out + idx0 + (size_t)(2 * pr) * HW : &g_trash_rec;
+          *dst = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+      }
+    asm volatile("" ::: "memory");
+    cur = nxt;
+    has_next = tile + 2 * t_step < t_end;
+    if (has_next) nxt = decode(tile + 2 * t_step);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // zero-record DMAs issued for the tile after the last: LDS must not be released under them
+}
+
+template <int DIL, int MB, int NKS, int RPW, int D>
+int launch_ring3(const H8Args& h, const slu_conv_h8_desc* d, hipStream_t st) {
+  constexpr int TH = 8 * RPW, PAD = DIL;
+  constexpr size_t nblk_b = (size_t)(2 * (TH + 2 * PAD) * (64 + 2 * PAD) + 63) / 64;
+  constexpr size_t lds = ((size_t)MB * NKS * 9 * 64 + (size_t)D * nblk_b * 64 + 64) * 16;      // + 3 * 32 MB floats static
+  static_assert(lds + 3 * 32 * MB * 4 <= 160 * 1024, "ring does not fit in LDS");
+  RingArgs a{};
+  a.x = h.src[0].ptr; a.G0 = h.src[0].G;
+  a.x1 = h.nsrc > 1 ? h.src[1].ptr : h.src[0].ptr; a.G1 = h.nsrc > 1 ? h.src[1].G : 0;
+  a.wpack = h.wpack; a.bias = h.bias; a.bn_a = h.bn_a; a.bn_b = h.bn_b;
+  a.slope = (h.has_act & 3) == 1 ? h.slope : 1.0f;
+  a.out = reinterpret_cast<uint4*>(d->out);
+  a.N = h.N; a.H = h.H; a.W = h.W;
+  a.tiles_x = (a.W + 63) / 64;
+  a.tiles_y = (a.H + TH - 1) / TH;
+  const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
+  if (nt <= 0 || nt > 0x7fffffffLL) return SLU_EUNSUPPORTED;
+  long long gx = 256;
+  if (gx > nt) gx = nt;
+  auto kern = ring3_h8_kernel<DIL, MB, NKS, RPW, D>;
+  static SluLdsGrant grant;
+  if (slu_grant_dynamic_lds(reinterpret_cast<const void*>(kern), lds, grant) != SLU_OK) return SLU_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds, st, a);
+  SLU_CHECK_LAUNCH();
+}
+
+// the layers ring3_h8_kernel covers: 3x3 (dil 1 / 2), one plain source of exactly 32 / 64 channels, 32 / 64 output channels, h8 output,
+// no residual, activation before BN only, and enough tiles to fill the chip.  Returns the instantiation's name, or nullptr.
+const char* ring3_name(const slu_conv_h8_desc* d, const H8Args& a, char* buf, size_t n) {
+  static const bool off = [] { const char* e = getenv("SLU_H8_RING3"); return e && e[0] == '0'; }();      // A/B switch
+  if (off || d->ksize != 3 || d->pad != d->dil || (d->dil != 1 && d->dil != 2) || a.nsrc < 1 || a.nsrc > 2) return nullptr;
+  int gsum = 0;
+  for (int s = 0; s < a.nsrc; ++s) {
+    if (a.src[s].scale || a.src[s].nb) return nullptr;
+    gsum += a.src[s].G;
+  }
+  if (gsum != a.Gin || (a.nsrc == 2 && (a.src[0].G & 1)) || a.out_f32 || d->resid || (a.has_act & ~1)) return nullptr;
+  if ((a.has_act & 1) && !(a.slope >= 0.0f && a.slope <= 1.0f)) return nullptr;      // LeakyReLU as max(t, slope t)
+  const int mb = a.Cout / 32, nks = a.Gin / 2;
+  const bool shape = (a.Cout == 32 || a.Cout == 64) && ((a.Gin == 4 || a.Gin == 8) || (a.Gin == 10 && a.Cout == 32 && d->dil == 1));
+  if (!shape) return nullptr;
+  const int rpw = (mb * nks >= 5 || (d->dil == 2 && mb * nks == 4)) ? 1 : 2;      // 16-row tiles where weights + the ring fit in LDS
+  if ((long long)a.N * ((a.H + 8 * rpw - 1) / (8 * rpw)) * ((a.W + 63) / 64) < 256) return nullptr;
+  snprintf(buf, n, "ring3_h8_kernel<%d, %d, %d, %d, %d>", d->dil, mb, nks, rpw, nks == 5 ? 4 : 3);
+  return buf;
+}
+
+int launch_ring3_any(const H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
+  const int mb = a.Cout / 32, nks = a.Gin / 2;
+  if (nks == 5) return launch_ring3<1, 1, 5, 1, 4>(a, d, st);                       // 80 -> 32: PixelShuffle output | skip (UpBlock.conv1, full resolution)
+  if (mb == 2 && nks == 4) return d->dil == 1 ? launch_ring3<1, 2, 4, 1, 3>(a, d, st) : launch_ring3<2, 2, 4, 1, 3>(a, d, st);
+  if (mb == 2 && nks == 2) return d->dil == 1 ? launch_ring3<1, 2, 2, 2, 3>(a, d, st) : launch_ring3<2, 2, 2, 1, 3>(a, d, st);
+  if (mb == 1 && nks == 4) return d->dil == 1 ? launch_ring3<1, 1, 4, 2, 3>(a, d, st) : launch_ring3<2, 1, 4, 1, 3>(a, d, st);
+  return d->dil == 1 ? launch_ring3<1, 1, 2, 2, 3>(a, d, st) : launch_ring3<2, 1, 2, 2, 3>(a, d, st);
+}
+
 constexpr size_t WRES_MAX_BYTES = 24 * 1024;
 
 // weights of all K-steps stay resident in LDS when they are small (full-resolution 32-channel layers)
@@ -1056,6 +1329,10 @@ extern "C" int slu_conv2d_h8_fwd(const slu_conv_h8_desc* d, slu_stream_t stream)
     if (a.nmblk <= 4) return launch_h8_1x1<4, 1>(a, d, st);
     return launch_h8_1x1<8, 1>(a, d, st);
   }
+  {
+    char nm[96];
+    if (ring3_name(d, a, nm, sizeof nm)) return launch_ring3_any(a, d, st);
+  }
   const bool sc = any_scale(d);
   if (a.out_f32) {      // fp32 NCHW output outside the streaming kernel's reach (odd H*W): 1x1 head only
     if (d->ksize != 1 || d->dil != 1 || d->pad != 0 || sc) return SLU_EUNSUPPORTED;
@@ -1080,6 +1357,7 @@ extern "C" int slu_conv2d_h8_kernel_name(const slu_conv_h8_desc* d, char* buf, s
     snprintf(buf, n, "conv1x1_h8_kernel<%d, %d>", mb, mb <= 2 ? 2 : 1);
     return SLU_OK;
   }
+  if (ring3_name(d, a, buf, n)) return SLU_OK;
   if (a.out_f32) {
     snprintf(buf, n, "conv_h8_kernel<1, 1, 0, 1, 1, 4, 1, false, false, true>");
     return SLU_OK;

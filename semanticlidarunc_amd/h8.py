@@ -6,6 +6,8 @@ kernels (fp16 operands, fp32 accumulate / epilogue); torch only owns the memory.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import NamedTuple, Optional, Sequence
 
@@ -204,7 +206,11 @@ def conv_tail_h8(a1: torch.Tensor, a2: torch.Tensor, w2x2: torch.Tensor, w1x1: t
     nbytes = n * h * w * 2.0 * (c + c + 3 * c + c) + 2.0 * c * c * (4 + 3)
     # what the fused kernel must move: a1, a2 (+ shortcut) in, out once, weights
     min_bytes = n * h * w * 2.0 * c * (3 + (1 if resid is not None else 0)) + 2.0 * c * c * (4 + 3)
-    name = {32: "tail_h8_kernel<1, 1, 8, 2, true>", 64: "tail_h8_kernel<2, 1, 8, 1, true>", 128: "tail_h8_kernel<2, 2, 4, 1, false>"}[c]
+    res = "true" if resid is not None else "false"       # the instantiation slu_conv_tail_h8_fwd launches (rocprofv3 reports the same name)
+    if os.environ.get("SLU_TAIL_V1") == "1":
+        name = {32: "tail_h8_kernel<1, 1, 8, 2, true>", 64: "tail_h8_kernel<2, 1, 8, 1, true>", 128: "tail_h8_kernel<2, 2, 4, 1, false>"}[c]
+    else:
+        name = {32: f"tail2_h8_kernel<1, 2, 3, {res}>", 64: f"tail2_h8_kernel<2, 1, 4, {res}>", 128: "tail_h8_kernel<2, 2, 4, 1, false>"}[c]
     ops.TIMING.append((name, flops, nbytes, e0, e1, min_bytes))
     ops.TIMING_TAGS.append(f"N{n} {c}->{c} k2d2 + {3 * c}->{c} k1 fused {h}x{w}")
     return out

@@ -116,6 +116,37 @@ def test_concat_scales_broadcast_and_fp32_head(cuda):
     _conv_case(cuda, 1, [32], 20, 5, 33, (1, 1, 0), seed=17, out_f32=True)                # odd H*W: tiled form of the head
 
 
+@pytest.mark.parametrize("dil", [1, 2])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64)])
+def test_deep_ring_3x3_full_resolution_layers(cuda, cin, cout, dil):
+    """ring3_h8_kernel (one plain source of 32 / 64 channels, 32 / 64 outputs, no residual, >= 256 tiles): whole tiles, ragged borders in
+    both directions, more tiles than one round of the persistent grid; the kernel name the ABI reports must be the ring form."""
+    fam = (3, dil, dil)
+    _conv_case(cuda, 4, [cin], cout, 64, 1024, fam, seed=20 + cin + cout + dil, resid=False)
+    _conv_case(cuda, 4, [cin], cout, 70, 1000, fam, seed=21 + cin + cout + dil, resid=False)     # partial tiles right and bottom
+    def launched(resid):
+        ops.TIMING, ops.TIMING_TAGS = [], []              # measurement mode records the instantiation slu_conv2d_h8_kernel_name reports
+        try:
+            _conv_case(cuda, 4, [cin], cout, 64, 1024, fam, seed=22 + cin + cout + dil, resid=resid)
+            return ops.TIMING[0][0]
+        finally:
+            ops.TIMING, ops.TIMING_TAGS = None, None
+    assert launched(False).startswith(f"ring3_h8_kernel<{dil}, {cout // 32}, {cin // 16}, ")
+    assert launched(True).startswith("conv_h8_kernel<")  # outside its reach (residual): the tiled kernel
+
+
+def test_deep_ring_3x3_two_plain_sources(cuda):
+    """UpBlock.conv1 at full resolution: PixelShuffle output (16 channels) | skip (64 channels) -> 32, both plain: ring form, 5 K-steps"""
+    ops.TIMING, ops.TIMING_TAGS = [], []
+    try:
+        _conv_case(cuda, 4, [16, 64], 32, 64, 1024, (3, 1, 1), seed=31, resid=False)
+        assert ops.TIMING[0][0] == "ring3_h8_kernel<1, 1, 5, 1, 4>", ops.TIMING[0][0]
+    finally:
+        ops.TIMING, ops.TIMING_TAGS = None, None
+    _conv_case(cuda, 5, [16, 64], 32, 61, 900, (3, 1, 1), seed=32, resid=False)
+    _conv_case(cuda, 4, [32, 32], 64, 64, 1024, (3, 2, 2), seed=33, resid=False)     # two sources inside the 64 -> 64 form
+
+
 def test_conv_argument_checks(cuda):
     x = h8.to_h8(torch.zeros(1, 8, 4, 32, device=cuda))
     w = h8.pack_conv_weight_h8(torch.zeros(8, 8, 3, 3, device=cuda))
