@@ -413,7 +413,34 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
       half8 sc;
       if constexpr (SCALED) sc = __builtin_bit_cast(half8, s_scale[spar * 64 + 2 * q + hh]);
       {
-        if constexpr (MB == 1) {
+        if constexpr (MB == 2 && WM == 2 && WN == 4) {
+          // the 8-wave 128-channel configuration (MFMA-bound layers): fragments of tap t+1 are read before the MFMAs of tap t issue, in THIS
+          // order -- sched_barrier pins it; with sched_group_barrier hints (below) the compiler still emits read, wait, MFMA, read, ...
+          // (+3 % on these layers; the other configurations spill with a second fragment set)
+          half8 af[2][MB], bf[2][NB];
+          auto read_frags = [&](int set, int tap) {
+            const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) af[set][i] = __builtin_bit_cast(half8, sa[i * a_stride + tap * 64]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              bf[set][b] = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+              if constexpr (SCALED) bf[set][b] *= sc;
+            }
+          };
+          read_frags(0, 0);
+#pragma unroll
+          for (int tap = 0; tap < T; ++tap) {
+            if (tap + 1 < T) read_frags((tap + 1) & 1, tap + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+              for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap & 1][i], bf[tap & 1][b], acc[i][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_after_tap(tap);
+          }
+        } else if constexpr (MB == 1) {
           // fragments of tap t+1 are read from LDS while the MFMAs of tap t issue (two register sets, one DS read per MFMA
           // slot); with MB = 2 the second set does not fit in 256 VGPRs next to the 128 accumulator registers
           half8 af[2][MB], bf[2][NB];
