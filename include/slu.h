@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 21
+#define SLU_ABI_VERSION 22
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -324,8 +324,16 @@ typedef struct slu_conv_tail_h8_desc {   /* HOST struct */
   float slopeB;
   const void* resid;
   void* out;
+  /* shortcut mode (exclusive with resid): the residual is LeakyReLU(conv1x1(sc_x) + sc_bias), rounded to fp16 -- the shortcut branch of a
+   * ResBlock (SalsaNext.py:52-53) computed inside the tail from the block's input instead of being written and read back.
+   * sc_x: h8 [N][sc_cin/8][H][W][8]; sc_w = slu_pack_conv_weight_h8 of [C][sc_cin][1][1]; slu_conv_tail_h8_shortcut_supported(C, sc_cin). */
+  const void *sc_x, *sc_w;
+  const float* sc_bias;
+  int32_t sc_cin, sc_hasact;
+  float sc_slope;
 } slu_conv_tail_h8_desc;
 int slu_conv_tail_h8_supported(int C, int H, int W);
+int slu_conv_tail_h8_shortcut_supported(int C, int sc_cin);
 int slu_conv_tail_h8_fwd(const slu_conv_tail_h8_desc* desc, slu_stream_t stream);
 
 /* Fused ResContextBlock on the h8 path (SalsaNext.py:10-39: conv1 1x1 + act -> shortcut; conv2 3x3 + act + bn1; conv3 3x3 dil 2 +

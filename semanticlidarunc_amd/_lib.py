@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -70,6 +70,8 @@ class ConvTailH8Desc(C.Structure):
         ("biasB", C.c_void_p), ("bnB_a", C.c_void_p), ("bnB_b", C.c_void_p),
         ("hasactB", C.c_int32), ("slopeB", C.c_float),
         ("resid", C.c_void_p), ("out", C.c_void_p),
+        ("sc_x", C.c_void_p), ("sc_w", C.c_void_p), ("sc_bias", C.c_void_p),
+        ("sc_cin", C.c_int32), ("sc_hasact", C.c_int32), ("sc_slope", C.c_float),
     ]
 
 
@@ -173,6 +175,7 @@ SIGNATURES = {
     "slu_groupnorm_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, c_f32p, c_f32p, c_f32p, c_stream]),
     "slu_spatial_softmax_gate": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_conv_tail_h8_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "slu_conv_tail_h8_shortcut_supported": (C.c_int, [C.c_int, C.c_int]),
     "slu_conv_tail_h8_fwd": (C.c_int, [C.POINTER(ConvTailH8Desc), c_stream]),
     "slu_head_mc_h8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_f32p, C.c_int, C.c_float, c_f32p, c_f32p, c_f32p,
                                  c_i64p, c_stream]),

@@ -41,6 +41,10 @@ struct TailArgs {
   const float *biasA, *bnA_a, *bnA_b, *biasB, *bnB_a, *bnB_b;
   float slopeA, slopeB;        // 1 = no activation
   const uint2* resid;          // h8 or nullptr
+  const uint4* sc_x;           // shortcut mode (tail2, C = 64): h8 [N][4][H][W], the block's input; resid = act(conv1x1(sc_x) + sc_bias) computed here
+  const uint4* sc_w;           // packed [C][32][1][1] weights
+  const float* sc_bias;
+  float slopeS;
   uint2* out;
   int N, H, W, G;              // G = C / 8 channel blocks
   int tiles_x, tiles_y;
@@ -328,7 +332,9 @@ __device__ __forceinline__ void tail2_static_for(F&& f, std::integer_sequence<in
   (f(std::integral_constant<int, Cs>{}), ...);
 }
 
-template <int MB, int RPW, int D, bool HASRES>
+// RES: 0 no residual; 1 residual tensor; 2 residual = LeakyReLU(conv1x1(sc_x) + sc_bias), the shortcut of a ResBlock whose input has 32
+// channels, computed in the epilogue from 2 K-steps of sc_x (4 record loads per lane instead of 8, and no shortcut tensor in HBM at all)
+template <int MB, int RPW, int D, int RES>
 __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
   constexpr int NWAVE = 8, T = 4, PAD = 1, DIL = 2, P = D - 1;
   constexpr int C = 32 * MB, NKS = 2 * MB;
@@ -336,7 +342,9 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
   constexpr int LW = TW + 2 * PAD, LH = TH + 2 * PAD, REC = LH * LW;
   constexpr int NBLK_B = (2 * REC + 63) / 64, NIB = (NBLK_B + NWAVE - 1) / NWAVE;     // a2 chunk: 64-record blocks, DMA slots per wave
   constexpr int BUFREC = NBLK_B * 64;
-  constexpr int NA1 = NKS * NB, NRES = HASRES ? MB * NB * 2 : 0, NST = MB * NB * 2;      // whole 16-byte records per lane, see epilogue B
+  constexpr bool HASRES = RES == 1;
+  constexpr int NKX = 2;                                                               // K-steps of the shortcut conv (32 input channels)
+  constexpr int NA1 = NKS * NB, NRES = RES == 1 ? MB * NB * 2 : (RES == 2 ? NKX * NB : 0), NST = MB * NB * 2;      // whole 16-byte records per lane, see epilogue B
   constexpr int CA = NKS / 2;                                                          // position that consumes a1 and loads the residual
   constexpr int A1WAIT = CA * NIB;                                                     // DMAs issued after the a1 loads, before their use
   constexpr int RESWAIT = (NKS - 1 - CA) * NIB;                                        // ... after the residual loads, before the epilogue
@@ -346,11 +354,12 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
   // NATIVE vector loads of the epilogue constants: the waitcnt pass guards an LDS read that carries no TBAA tag (a HIP float4 / uint4
   // struct copied by value) with s_waitcnt vmcnt(0) while any LDS-DMA is in flight -- which would drain the ring; tagged reads are left
   // to the counted waits of this kernel
-  __shared__ __attribute__((aligned(16))) float s_epi[6 * C];
+  __shared__ __attribute__((aligned(16))) float s_epi[7 * C];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* s_w2 = reinterpret_cast<uint4*>(smem);                     // [MB][NKS][4][64]
   uint4* s_w1 = s_w2 + MB * NKS * T * 64;                           // [MB][3 NKS][64], the a3 third K-permuted
-  uint4* s_ring = s_w1 + MB * 3 * NKS * 64;                         // [D][BUFREC]
+  uint4* s_ws = s_w1 + MB * 3 * NKS * 64;                           // RES == 2: [MB][NKX][64] shortcut weights
+  uint4* s_ring = s_ws + (RES == 2 ? MB * NKX * 64 : 0);            // [D][BUFREC]
   uint4* s_trash = s_ring + D * BUFREC;                             // [64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave;
@@ -375,7 +384,10 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
     s_epi[3 * C + tid] = a.biasB ? a.biasB[tid] : 0.0f;
     s_epi[4 * C + tid] = a.bnB_a ? a.bnB_a[tid] : 1.0f;
     s_epi[5 * C + tid] = a.bnB_a ? a.bnB_b[tid] : 0.0f;
+    s_epi[6 * C + tid] = (RES == 2 && a.sc_bias) ? a.sc_bias[tid] : 0.0f;
   }
+  if constexpr (RES == 2)
+    for (int blk = wave; blk < MB * NKX; blk += NWAVE) SLU_GLDS16_T(a.sc_w + (size_t)blk * 64 + lane, s_ws + blk * 64);
   for (int blk = wave; blk < MB * NKS * T; blk += NWAVE) SLU_GLDS16_T(a.w2 + (size_t)blk * 64 + lane, s_w2 + blk * 64);
   for (int blk = wave; blk < MB * 3 * NKS; blk += NWAVE) {
     const int k = blk % (3 * NKS);
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
   for (int c = 0; c < P; ++c) stage(cur, c, c, !(a.dbg & 1));
   int rslot = 0, wslot = P % D;
   bool first = true;
-  const float2v slA = {a.slopeA, a.slopeA}, slB = {a.slopeB, a.slopeB};
+  const float2v slA = {a.slopeA, a.slopeA}, slB = {a.slopeB, a.slopeB}, slS = {a.slopeS, a.slopeS};
   const f32x4v* se4p = reinterpret_cast<const f32x4v*>(s_epi) + hh;
   auto se4 = [&](int k) { return se4p[k]; };
 
@@ -442,6 +454,7 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
     f32x16 acc3[MB][NB], acco[MB][NB];
     u32x4v a1r[NKS][NB];
     u32x4v res[HASRES ? MB : 1][HASRES ? NB : 1][2];
+    u32x4v xs[RES == 2 ? NKX : 1][RES == 2 ? NB : 1];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -498,6 +511,16 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
 #pragma unroll
               for (int i = 0; i < MB; ++i) acco[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], __builtin_bit_cast(half8, a1r[k][b]), acco[i][b], 0, 0, 0);
           }
+        }
+        if constexpr (RES == 2) {     // the block's input: K-step k of pixel block b = the record of channel block 2 k + hh (as for a1)
+          const unsigned long long base = reinterpret_cast<unsigned long long>(a.sc_x) + 16ull * ((size_t)cur.n * (2 * NKX) * HW);
+#pragma unroll
+          for (int k = 0; k < NKX; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              const unsigned vo = voff[b] + (unsigned)((2 * k + hh) * HW * 16);
+              asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(xs[k][b]) : "v"(vo), "s"(base) : "memory");
+            }
         }
         if constexpr (HASRES) {       // whole records: lane (jj, hh) loads record 2 pr + hh of channel block i (un-swapped in epilogue B)
           const unsigned long long base = reinterpret_cast<unsigned long long>(a.resid) + img16;
@@ -589,6 +612,10 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
                      "+v"(res[(2 / NB) % MB][2 % NB][0]), "+v"(res[(2 / NB) % MB][2 % NB][1]), "+v"(res[(3 / NB) % MB][3 % NB][0]), "+v"(res[(3 / NB) % MB][3 % NB][1])
                    : "n"(RESWAIT));
     }
+    if constexpr (RES == 2) {
+      static_assert(NKX * NB == 4, "the wait below names its registers");
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xs[0][0]), "+v"(xs[0][NB - 1]), "+v"(xs[NKX - 1][0]), "+v"(xs[NKX - 1][NB - 1]) : "n"(RESWAIT));
+    }
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -596,6 +623,14 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
         const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
         const bool ok = gy < a.H && gx < a.W;
         const size_t idx0 = ok ? ((size_t)cur.n * a.G + i * 4 + hh) * HW + (size_t)gy * a.W + gx : 0;
+        f32x16 sacc;
+        if constexpr (RES == 2) {      // the shortcut's 32 x 32 tile: 2 MFMAs, in the accumulator layout of acc_out
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+          for (int k = 0; k < NKX; ++k)
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, s_ws[(i * NKX + k) * 64 + lane]), __builtin_bit_cast(half8, xs[k][b]), sacc, 0, 0, 0);
+        }
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           unsigned rw[4] = {0u, 0u, 0u, 0u};       // residual words: [0..1] for q = 2 pr, [2..3] for q = 2 pr + 1
@@ -621,6 +656,16 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
               t0 += __builtin_convertvector(__builtin_bit_cast(half2v, rw[2 * q2]), float2v);
               t1 += __builtin_convertvector(__builtin_bit_cast(half2v, rw[2 * q2 + 1]), float2v);
             }
+            if constexpr (RES == 2) {      // rounded to fp16 where the separate launch stores the shortcut
+              const f32x4v bs = se4(6 * C / 4 + c4);
+              float2v u0 = {sacc[4 * q], sacc[4 * q + 1]}, u1 = {sacc[4 * q + 2], sacc[4 * q + 3]};
+              u0 += float2v{bs.x, bs.y};
+              u1 += float2v{bs.z, bs.w};
+              u0 = __builtin_elementwise_max(u0, u0 * slS);
+              u1 = __builtin_elementwise_max(u1, u1 * slS);
+              t0 += __builtin_convertvector(__builtin_convertvector(u0, half2v), float2v);
+              t1 += __builtin_convertvector(__builtin_convertvector(u1, half2v), float2v);
+            }
             hw[2 * q2] = __builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v));
             hw[2 * q2 + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v));
           }
@@ -638,19 +683,19 @@ __global__ __launch_bounds__(512, 2) void tail2_h8_kernel(const TailArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-record DMAs issued for the tile after the last: LDS must not be released under them
 }
 
-template <int MB, int RPW, int D, bool HASRES>
+template <int MB, int RPW, int D, int RES>
 int launch_tail2(TailArgs& a, hipStream_t st) {
   constexpr int TH = 8 * RPW, C = 32 * MB, NKS = 2 * MB;
   constexpr size_t nblk_b = (size_t)(2 * (TH + 2) * 66 + 63) / 64;
-  constexpr size_t lds = ((size_t)MB * NKS * 4 * 64 + (size_t)MB * 3 * NKS * 64 + (size_t)D * nblk_b * 64 + 64) * 16;      // + 6 C floats static
-  static_assert(lds + 6 * C * 4 <= 160 * 1024, "ring does not fit in LDS");
+  constexpr size_t lds = ((size_t)MB * NKS * 4 * 64 + (size_t)MB * 3 * NKS * 64 + (RES == 2 ? (size_t)MB * 2 * 64 : 0) + (size_t)D * nblk_b * 64 + 64) * 16;      // + 7 C floats static
+  static_assert(lds + 7 * C * 4 <= 160 * 1024, "ring does not fit in LDS");
   a.tiles_x = (a.W + 63) / 64;
   a.tiles_y = (a.H + TH - 1) / TH;
   const long long nt = (long long)a.tiles_x * a.tiles_y * a.N;
   if (nt <= 0 || nt > 0x7fffffffLL) return SLU_EUNSUPPORTED;
   long long gx = 256;
   if (gx > nt) gx = nt;
-  auto kern = tail2_h8_kernel<MB, RPW, D, HASRES>;
+  auto kern = tail2_h8_kernel<MB, RPW, D, RES>;
   static SluLdsGrant grant;
   if (slu_grant_dynamic_lds(reinterpret_cast<const void*>(kern), lds, grant) != SLU_OK) return SLU_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds, st, a);
@@ -679,6 +724,8 @@ int launch_tail(TailArgs& a, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int slu_conv_tail_h8_shortcut_supported(int C, int sc_cin) { return C == 64 && sc_cin == 32 ? 1 : 0; }
+
 extern "C" int slu_conv_tail_h8_supported(int C, int H, int W) { return (C == 32 || C == 64 || C == 128) && H > 0 && W > 0 ? 1 : 0; }
 
 extern "C" int slu_conv_tail_h8_fwd(const slu_conv_tail_h8_desc* d, slu_stream_t stream) {
@@ -704,8 +751,17 @@ extern "C" int slu_conv_tail_h8_fwd(const slu_conv_tail_h8_desc* d, slu_stream_t
   a.dbg = dbg;
   hipStream_t st = slu_stream(stream);
   static const bool v1 = [] { const char* e = getenv("SLU_TAIL_V1"); return e && e[0] == '1'; }();     // A/B switch: the round-1 kernel
-  if (!v1 && d->C == 32) return a.resid ? launch_tail2<1, 2, 3, true>(a, st) : launch_tail2<1, 2, 3, false>(a, st);
-  if (!v1 && d->C == 64) return a.resid ? launch_tail2<2, 1, 4, true>(a, st) : launch_tail2<2, 1, 4, false>(a, st);
+  if (d->sc_x) {      // shortcut mode
+    if (d->resid || !d->sc_w || !slu_conv_tail_h8_shortcut_supported(d->C, d->sc_cin) || (((uintptr_t)d->sc_x | (uintptr_t)d->sc_w) & 15)) return SLU_EINVAL;
+    if (d->sc_hasact && !(d->sc_slope >= 0.0f && d->sc_slope <= 1.0f)) return SLU_EINVAL;
+    a.sc_x = reinterpret_cast<const uint4*>(d->sc_x);
+    a.sc_w = reinterpret_cast<const uint4*>(d->sc_w);
+    a.sc_bias = d->sc_bias;
+    a.slopeS = d->sc_hasact ? d->sc_slope : 1.0f;
+    return launch_tail2<2, 1, 4, 2>(a, st);
+  }
+  if (!v1 && d->C == 32) return a.resid ? launch_tail2<1, 2, 3, 1>(a, st) : launch_tail2<1, 2, 3, 0>(a, st);
+  if (!v1 && d->C == 64) return a.resid ? launch_tail2<2, 1, 4, 1>(a, st) : launch_tail2<2, 1, 4, 0>(a, st);
   if (d->C == 32) return launch_tail<1, 1, 8, 2, true>(a, st);
   if (d->C == 64) return launch_tail<2, 1, 8, 1, true>(a, st);
   return launch_tail<2, 2, 4, 1, false>(a, st);

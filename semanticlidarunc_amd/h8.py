@@ -155,13 +155,19 @@ def conv_tail_supported(channels: int, h: int, w: int) -> bool:
     return bool(_lib.load().slu_conv_tail_h8_supported(int(channels), int(h), int(w)))
 
 
+def conv_tail_shortcut_supported(channels: int, cin: int) -> bool:
+    return bool(_lib.load().slu_conv_tail_h8_shortcut_supported(int(channels), int(cin)))
+
+
 def conv_tail_h8(a1: torch.Tensor, a2: torch.Tensor, w2x2: torch.Tensor, w1x1: torch.Tensor,
                  bias_a: Optional[torch.Tensor], slope_a: Optional[float], bn_a: Optional[tuple],
                  bias_b: Optional[torch.Tensor], slope_b: Optional[float], bn_b: Optional[tuple],
-                 resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 resid: Optional[torch.Tensor] = None, shortcut: Optional[tuple] = None) -> torch.Tensor:
     """The fused tail of a SalsaNext block (slu_conv_tail_h8_fwd):
         a3  = bn_a(leaky(conv2x2_dil2(a2) + bias_a));   out = [resid +] bn_b(leaky(conv1x1(cat(a1, a2, a3)) + bias_b))
-    a1 / a2 / resid: h8 [N, C/8, H, W, 8]; w2x2 / w1x1: pack_conv_weight_h8 of [C, C, 2, 2] / [C, 3C, 1, 1]; bn_*: (scale, shift) or None."""
+    a1 / a2 / resid: h8 [N, C/8, H, W, 8]; w2x2 / w1x1: pack_conv_weight_h8 of [C, C, 2, 2] / [C, 3C, 1, 1]; bn_*: (scale, shift) or None.
+    shortcut = (x, wpack, bias, slope, cin) instead of resid: resid = leaky(conv1x1(x) + bias) computed inside the kernel from the block's input
+    x (h8 [N, cin/8, H, W, 8], wpack = pack_conv_weight_h8 of [C, cin, 1, 1]); conv_tail_shortcut_supported(C, cin)."""
     lib = _lib.load()
     _req_h8(a1, "a1")
     _req_h8(a2, "a2")
@@ -186,8 +192,25 @@ def conv_tail_h8(a1: torch.Tensor, a2: torch.Tensor, w2x2: torch.Tensor, w1x1: t
         _req_h8(resid, "resid")
         if resid.shape != a1.shape:
             raise RuntimeError(f"resid: expected {tuple(a1.shape)}, got {tuple(resid.shape)}")
+    if shortcut is not None:
+        sx, sw, sb, sslope, scin = shortcut
+        if resid is not None:
+            raise RuntimeError("conv_tail_h8: resid and shortcut are exclusive")
+        if not conv_tail_shortcut_supported(c, scin):
+            raise RuntimeError(f"conv_tail_h8: shortcut {scin} -> {c} is not covered (run the 1x1 conv and pass resid)")
+        _req_h8(sx, "shortcut.x")
+        _req(sw, "shortcut.w", torch.uint8)
+        if tuple(sx.shape) != (n, scin // 8, h, w, 8) or sw.numel() != lib.slu_packed_weight_bytes_h8(c, scin, 1):
+            raise RuntimeError("conv_tail_h8: shortcut operand sizes do not match")
+        if sb is not None:
+            _req(sb, "shortcut.bias")
+            if sb.numel() != c:
+                raise RuntimeError(f"shortcut.bias: expected {c} elements, got {sb.numel()}")
     out = torch.empty_like(a1)
     d.a1, d.a2, d.N, d.H, d.W, d.C = a1.data_ptr(), a2.data_ptr(), n, h, w, c
+    if shortcut is not None:
+        d.sc_x, d.sc_w, d.sc_bias, d.sc_cin = sx.data_ptr(), sw.data_ptr(), _ptr(sb), int(scin)
+        d.sc_hasact, d.sc_slope = (0, 0.0) if sslope is None else (1, float(sslope))
     d.w2x2, d.w1x1 = w2x2.data_ptr(), w1x1.data_ptr()
     d.biasA, d.bnA_a, d.bnA_b = _ptr(bias_a), _ptr(None if bn_a is None else bn_a[0]), _ptr(None if bn_a is None else bn_a[1])
     d.biasB, d.bnB_a, d.bnB_b = _ptr(bias_b), _ptr(None if bn_b is None else bn_b[0]), _ptr(None if bn_b is None else bn_b[1])
@@ -202,17 +225,19 @@ def conv_tail_h8(a1: torch.Tensor, a2: torch.Tensor, w2x2: torch.Tensor, w1x1: t
     check(lib.slu_conv_tail_h8_fwd(C.byref(d), _stream()), "slu_conv_tail_h8_fwd")
     e1.record()
     # the layer-granular convention of SURVEY 8(d): both convs read their inputs and write their outputs once
-    flops = 2.0 * c * c * (4 + 3) * n * h * w
-    nbytes = n * h * w * 2.0 * (c + c + 3 * c + c) + 2.0 * c * c * (4 + 3)
-    # what the fused kernel must move: a1, a2 (+ shortcut) in, out once, weights
-    min_bytes = n * h * w * 2.0 * c * (3 + (1 if resid is not None else 0)) + 2.0 * c * c * (4 + 3)
-    res = "true" if resid is not None else "false"       # the instantiation slu_conv_tail_h8_fwd launches (rocprofv3 reports the same name)
-    if os.environ.get("SLU_TAIL_V1") == "1":
+    scin = shortcut[4] if shortcut is not None else 0
+    flops = 2.0 * c * (c * (4 + 3) + scin) * n * h * w
+    # layer-granular convention: every conv reads its inputs and writes its output once (the shortcut conv: x in, shortcut out)
+    nbytes = n * h * w * 2.0 * (c + c + 3 * c + c + (scin + c if shortcut is not None else 0)) + 2.0 * c * (c * (4 + 3) + scin)
+    # what the fused kernel must move: a1, a2 (+ the residual, or the shortcut's input) in, out once, weights
+    min_bytes = n * h * w * 2.0 * (c * 3 + (c if resid is not None else 0) + scin) + 2.0 * c * (c * (4 + 3) + scin)
+    res = 2 if shortcut is not None else (1 if resid is not None else 0)      # the instantiation slu_conv_tail_h8_fwd launches (rocprofv3 reports the same name)
+    if os.environ.get("SLU_TAIL_V1") == "1" and shortcut is None:
         name = {32: "tail_h8_kernel<1, 1, 8, 2, true>", 64: "tail_h8_kernel<2, 1, 8, 1, true>", 128: "tail_h8_kernel<2, 2, 4, 1, false>"}[c]
     else:
         name = {32: f"tail2_h8_kernel<1, 2, 3, {res}>", 64: f"tail2_h8_kernel<2, 1, 4, {res}>", 128: "tail_h8_kernel<2, 2, 4, 1, false>"}[c]
     ops.TIMING.append((name, flops, nbytes, e0, e1, min_bytes))
-    ops.TIMING_TAGS.append(f"N{n} {c}->{c} k2d2 + {3 * c}->{c} k1 fused {h}x{w}")
+    ops.TIMING_TAGS.append(f"N{n} {c}->{c} k2d2 + {3 * c}->{c} k1" + (f" + {scin}->{c} k1 shortcut" if shortcut is not None else "") + f" fused {h}x{w}")
     return out
 
 

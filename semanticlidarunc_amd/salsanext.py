@@ -43,6 +43,7 @@ _FUSE_TAIL = os.environ.get("SLU_FUSE_TAIL", "1") != "0"
 # the fused kernel also covers 128 channels, but there (MFMA-bound layers, 4-row tiles) it measured slower than the two launches
 _FUSE_TAIL_MAX_C = int(os.environ.get("SLU_FUSE_TAIL_MAX_C", "64"))
 # half-precision inference: a ResContextBlock (1x1 -> 3x3 -> 3x3 dilated + shortcut) as one launch (0: three launches; A/B switch)
+_FUSE_SHORTCUT = os.environ.get("SLU_FUSE_SHORTCUT", "1") != "0"      # A/B: ResBlock shortcut conv inside the fused tail
 _FUSE_CTX = os.environ.get("SLU_FUSE_CTX", "1") != "0"
 # half-precision MC inference: head conv + softmax / entropy / MI reduction over the T passes as one launch (0: logits + slu_mc_reduce)
 _FUSE_HEAD_MC = os.environ.get("SLU_FUSE_HEAD_MC", "1") != "0"
@@ -116,14 +117,17 @@ class _FusedBlock(nn.Module):
             p = cache[str(id(conv))] = _Prepared()
         return p
 
-    def _run_tail(self, conv_a: nn.Conv2d, bn_a, conv_b: nn.Conv2d, bn_b, a1, a2, resid=None):
+    def _tail_is_fused(self, conv_a: nn.Conv2d, conv_b: nn.Conv2d, a1) -> bool:
+        c = conv_a.out_channels
+        return bool(_FUSE_TAIL and a1.dtype == torch.float16 and a1.dim() == 5 and conv_a.kernel_size == (2, 2) and conv_a.dilation == (2, 2)
+                    and conv_b.kernel_size == (1, 1) and conv_b.in_channels == 3 * c and conv_b.out_channels == c
+                    and c <= _FUSE_TAIL_MAX_C and h8.conv_tail_supported(c, a1.shape[2], a1.shape[3]))
+
+    def _run_tail(self, conv_a: nn.Conv2d, bn_a, conv_b: nn.Conv2d, bn_b, a1, a2, resid=None, shortcut=None):
         """The last two layers of a block, `conv_b(cat(a1, a2, conv_a(a2)))`, each followed by LeakyReLU and eval BatchNorm.
         Half-precision inference with 32 / 64 channels: one fused launch that keeps conv_a's output on chip (csrc/conv_tail_h8.hip);
         otherwise the two layers one after the other."""
-        c = conv_a.out_channels
-        if (_FUSE_TAIL and a1.dtype == torch.float16 and a1.dim() == 5 and conv_a.kernel_size == (2, 2) and conv_a.dilation == (2, 2)
-                and conv_b.kernel_size == (1, 1) and conv_b.in_channels == 3 * c and conv_b.out_channels == c
-                and c <= _FUSE_TAIL_MAX_C and h8.conv_tail_supported(c, a1.shape[2], a1.shape[3])):
+        if self._tail_is_fused(conv_a, conv_b, a1):
             packs, folded = [], []
             for conv, bn in ((conv_a, bn_a), (conv_b, bn_b)):
                 p = self._prepared(conv)
@@ -134,8 +138,19 @@ class _FusedBlock(nn.Module):
                 packs.append(p.wpack8)
                 fa, fb = self._folded_bn(p, bn)
                 folded.append(None if fa is None else (fa, fb))
+            sc = None
+            if shortcut is not None:      # (x, conv): the block's shortcut branch leaky(conv(x)) computed inside the tail (h8.conv_tail_h8)
+                sx, sconv = shortcut
+                p = self._prepared(sconv)
+                wkey = _tkey(sconv.weight)
+                if p.key8 != wkey:
+                    p.wpack8 = h8.pack_conv_weight_h8(sconv.weight.detach().contiguous())
+                    p.key8 = wkey
+                sc = (sx, p.wpack8, None if sconv.bias is None else sconv.bias.detach(), _SLOPE, sconv.in_channels)
             return h8.conv_tail_h8(a1, a2, packs[0], packs[1], None if conv_a.bias is None else conv_a.bias.detach(), _SLOPE, folded[0],
-                                   None if conv_b.bias is None else conv_b.bias.detach(), _SLOPE, folded[1], resid=resid)
+                                   None if conv_b.bias is None else conv_b.bias.detach(), _SLOPE, folded[1], resid=resid, shortcut=sc)
+        if shortcut is not None:
+            resid = self._run(shortcut[1], None, [ConvSource(shortcut[0])])
         a3 = self._run(conv_a, bn_a, [ConvSource(a2)])
         return self._run(conv_b, bn_b, [ConvSource(a1), ConvSource(a2), ConvSource(a3)], resid=resid)
 
@@ -249,9 +264,16 @@ class ResBlock(_FusedBlock):
     def features(self, x):
         """The block up to (not including) dropout / pooling: deterministic given x."""
         src = [ConvSource(x)]
-        shortcut = self._run(self.conv1, None, src)
+        # half precision, 32 -> 64 (resBlock1): the shortcut conv runs inside the fused tail, from x, and its tensor never exists
+        fuse_sc = (_FUSE_SHORTCUT and x.dtype == torch.float16 and x.dim() == 5 and x.shape[1] * 8 == self.conv1.in_channels
+                   and h8.conv_tail_shortcut_supported(self.conv1.out_channels, self.conv1.in_channels))
+        shortcut = None if fuse_sc else self._run(self.conv1, None, src)
         a1 = self._run(self.conv2, self.bn1, src)
         a2 = self._run(self.conv3, self.bn2, [ConvSource(a1)])
+        if fuse_sc and self._tail_is_fused(self.conv4, self.conv5, a1):
+            return self._run_tail(self.conv4, self.bn3, self.conv5, self.bn4, a1, a2, shortcut=(x, self.conv1))
+        if shortcut is None:
+            shortcut = self._run(self.conv1, None, src)
         return self._run_tail(self.conv4, self.bn3, self.conv5, self.bn4, a1, a2, resid=shortcut)
 
     def forward(self, x, _scales=None, _name=""):

@@ -51,6 +51,36 @@ def test_tail_matches_unfused_and_fp32(cuda, c):
     _case(cuda, c, 70, 8, 64, True, 5)                                     # more tiles than one round of workgroups... per image 1
 
 
+@pytest.mark.parametrize("n,hh,ww,seed", [(2, 64, 256, 11), (1, 19, 150, 12), (6, 64, 2048, 13)])
+def test_tail_with_the_shortcut_conv_inside(cuda, n, hh, ww, seed):
+    """ResBlock 32 -> 64: out = bnB(leaky(conv1x1(cat))) + leaky(conv1x1(x) + b), the shortcut computed inside the tail from x (never stored),
+    == the same tail fed the shortcut tensor of a separate conv2d_h8 launch (same fp16 rounding of the shortcut: 2e-3 of the scale, fp32
+    summation order of two K-steps), and the CPU oracle's fused_conv on the fp16-rounded operands (3e-3)."""
+    c, cx = 64, 32
+    g = torch.Generator(device=cuda).manual_seed(seed)
+    rn = lambda *sh: torch.randn(*sh, device=cuda, generator=g)
+    x, a1, a2 = rn(n, cx, hh, ww), rn(n, c, hh, ww), rn(n, c, hh, ww)
+    w2, w1, ws = rn(c, c, 2, 2) / (4 * c) ** 0.5, rn(c, 3 * c, 1, 1) / (3 * c) ** 0.5, rn(c, cx, 1, 1) / cx ** 0.5
+    ba, bb, bs = rn(c) * 0.1, rn(c) * 0.1, rn(c) * 0.1
+    bna, bnb = (torch.rand(c, device=cuda, generator=g) + 0.5, rn(c) * 0.1), (torch.rand(c, device=cuda, generator=g) + 0.5, rn(c) * 0.1)
+    hx, h1, h2 = h8.to_h8(x), h8.to_h8(a1), h8.to_h8(a2)
+    p2, p1, ps = h8.pack_conv_weight_h8(w2), h8.pack_conv_weight_h8(w1), h8.pack_conv_weight_h8(ws)
+    assert h8.conv_tail_shortcut_supported(64, 32) and not h8.conv_tail_shortcut_supported(32, 32) and not h8.conv_tail_shortcut_supported(64, 64)
+    fused = h8.from_h8(h8.conv_tail_h8(h1, h2, p2, p1, ba, 0.01, bna, bb, 0.01, bnb, shortcut=(hx, ps, bs, 0.01, cx)), c).cpu()
+    sc = h8.conv2d_h8([h8.H8Source(hx)], ps, cx, c, 1, 1, 0, bias=bs, slope=0.01)
+    sep = h8.from_h8(h8.conv_tail_h8(h1, h2, p2, p1, ba, 0.01, bna, bb, 0.01, bnb, resid=sc), c).cpu()
+    q = lambda t: t.half().float().cpu()
+    pair = lambda pr: (pr[0].cpu(), pr[1].cpu())
+    osc = osalsa.fused_conv([(q(x), None, False)], q(ws), bs.cpu(), 0, 1, 0.01).half().float()
+    a3 = osalsa.fused_conv([(q(a2), None, False)], q(w2), ba.cpu(), 1, 2, 0.01, *pair(bna)).half().float()
+    ref = osalsa.fused_conv([(q(a1), None, False), (q(a2), None, False), (a3, None, False)], q(w1), bb.cpu(), 0, 1, 0.01, *pair(bnb), resid=osc)
+    scale = float(ref.abs().max())
+    assert float((fused - sep).abs().max()) <= 2e-3 * scale, (n, hh, ww, float((fused - sep).abs().max()), scale)
+    assert float((fused - ref).abs().max()) <= 3e-3 * scale, (n, hh, ww, float((fused - ref).abs().max()), scale)
+    with pytest.raises(RuntimeError):      # exclusive with resid
+        h8.conv_tail_h8(h1, h2, p2, p1, ba, 0.01, bna, bb, 0.01, bnb, resid=sc, shortcut=(hx, ps, bs, 0.01, cx))
+
+
 def test_tail_many_tiles_and_argument_checks(cuda):
     _case(cuda, 64, 6, 64, 2048, True, 6)                                  # 6 x 8 x 32 = 1536 tiles: six rounds of the persistent grid
     _case(cuda, 32, 5, 64, 2048, False, 7)
