@@ -306,22 +306,32 @@ class UpBlock(_FusedBlock):
         self.bn4 = nn.BatchNorm2d(out_filters)
         self.dropout3 = nn.Dropout2d(p=dropout_rate)
 
+    def _compose_scales(self, x_scale, d1, d2):
+        """(multiplier of the stored x [n, in_filters], multiplier of the skip [n, skip channels]) from the producer's deferred multiplier
+        and this block's dropout1 / dropout2 draws: dropout1 acts on the shuffled x, dropout2 on cat(shuffled x, skip) (SalsaNext.py:141-149)."""
+        cu = self.in_filters // 4
+        sx, ss = x_scale, None
+        up = d1
+        if d2 is not None:
+            up = _mul(up, d2[:, :cu])
+            ss = d2[:, cu:].contiguous()
+        if up is not None:      # shuffled channel c is fed by stored channels 4c..4c+3
+            sx = _mul(sx, up.repeat_interleave(4, dim=1))
+        return sx, ss
+
     def forward(self, x, skip, x_scale=None, _scales=None, _name="", skip_nbatch=0):
         """x is read through PixelShuffle(2); x_scale is the producer's deferred dropout multiplier.
         skip_nbatch > 0: `skip` holds that many images shared by the stacked MC passes.
         Returns (out, deferred multiplier of dropout3 or None)."""
         n, cx, dev = x.shape[0], self.in_filters, x.device
         cu, cs = cx // 4, self.conv1.in_channels - cx // 4
-        sx, ss = x_scale, None
-        if self.drop_out:
-            d1 = _draw(self.dropout1, n, cu, dev, _scales, _name + ".dropout1")
-            d2 = _draw(self.dropout2, n, cu + cs, dev, _scales, _name + ".dropout2")
-            up = d1
-            if d2 is not None:
-                up = _mul(up, d2[:, :cu])
-                ss = d2[:, cu:].contiguous()
-            if up is not None:      # shuffled channel c is fed by stored channels 4c..4c+3
-                sx = _mul(sx, up.repeat_interleave(4, dim=1))
+        if _scales is not None and _scales.get(_name + "._composed"):      # composed with the draws, on the side stream (SalsaNext._predraw_dropout)
+            sx, ss = _scales.get(_name + "._sx"), _scales.get(_name + "._ss")
+        elif self.drop_out:
+            sx, ss = self._compose_scales(x_scale, _draw(self.dropout1, n, cu, dev, _scales, _name + ".dropout1"),
+                                          _draw(self.dropout2, n, cu + cs, dev, _scales, _name + ".dropout2"))
+        else:
+            sx, ss = x_scale, None
         if x.dtype == torch.float16:
             # h8: PixelShuffle is a (tiny) data-movement launch that also applies the producer's multiplier and dropout1/2
             xs = h8.pixel_shuffle_h8(x, None if sx is None else sx.contiguous())
@@ -463,6 +473,17 @@ class SalsaNext(_FusedBlock):
                 if s is not None:
                     s.record_stream(main)
                     out[key] = s
+            # the multipliers the decoder's convs actually consume are products of these masks (UpBlock.forward): compose them here too, so
+            # that the main stream carries no tiny elementwise launches between the convs
+            prod = out.get("resBlock5.dropout")
+            for blk in ("upBlock1", "upBlock2", "upBlock3", "upBlock4"):
+                sx, ss = getattr(self, blk)._compose_scales(prod, out.get(f"{blk}.dropout1"), out.get(f"{blk}.dropout2"))
+                for key, t in ((f"{blk}._sx", sx), (f"{blk}._ss", ss)):
+                    if t is not None:
+                        t.record_stream(main)
+                        out[key] = t
+                out[f"{blk}._composed"] = True
+                prod = out.get(f"{blk}.dropout3")
         self.__dict__["_drop_event"] = side.record_event()
         return out
 
