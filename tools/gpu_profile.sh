@@ -5,12 +5,17 @@ set -eo pipefail
 OUT=${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-echo "[1/5] bench.py (default)"; timeout -k 10 600 python bench.py --breakdown "$OUT/bench_f16_conv_breakdown_hipevents.txt" > "$OUT/bench_f16_line.json" 2> "$OUT/bench_f16.err"
+echo "[1/6] bench.py (default)"; timeout -k 10 600 python bench.py --breakdown "$OUT/bench_f16_conv_breakdown_hipevents.txt" > "$OUT/bench_f16_line.json" 2> "$OUT/bench_f16.err"
 tail -c 600 "$OUT/bench_f16_line.json"; echo
-echo "[2/5] rocprofv3 --kernel-trace --stats"; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py --no-cpu-baseline --no-train-step > "$OUT/bench_f16_line_under_rocprof.json" 2> "$OUT/rocprof_stats.err"
+echo "[2/6] rocprofv3 --kernel-trace --stats"; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py --no-cpu-baseline --no-train-step > "$OUT/bench_f16_line_under_rocprof.json" 2> "$OUT/rocprof_stats.err"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_f16_kernel_stats.csv"
-echo "[3/5] PMC FETCH_SIZE"; SLU_CONV_PRECISION=f16 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_rd" -- python3 tools/prof_forward.py 64 2 mc > "$OUT/pmc_rd.log" 2>&1
-echo "[4/5] PMC WRITE_SIZE"; SLU_CONV_PRECISION=f16 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_wr" -- python3 tools/prof_forward.py 64 2 mc > "$OUT/pmc_wr.log" 2>&1
-echo "[5/5] tables"; python tools/pmc_table.py "$OUT/pmc_rd" "$OUT/pmc_wr" --json="$OUT/pmc_f16_traffic_N64.json" --meta-images=64 > "$OUT/pmc_f16_forward_N64_fetch_write.txt"
+echo "[3/6] PMC FETCH_SIZE"; SLU_CONV_PRECISION=f16 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_rd" -- python3 tools/prof_forward.py 64 2 mc > "$OUT/pmc_rd.log" 2>&1
+echo "[4/6] PMC WRITE_SIZE"; SLU_CONV_PRECISION=f16 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_wr" -- python3 tools/prof_forward.py 64 2 mc > "$OUT/pmc_wr.log" 2>&1
+echo "[5/6] tables"; python tools/pmc_table.py "$OUT/pmc_rd" "$OUT/pmc_wr" --json="$OUT/pmc_f16_traffic_N64.json" --meta-images=64 > "$OUT/pmc_f16_forward_N64_fetch_write.txt"
 rm -rf "$OUT/stats" "$OUT/pmc_rd" "$OUT/pmc_wr"
+echo "[6/6] training step: rocprofv3 kernel stats of tools/train_bench.py, weight-gradient kernels per shape"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/tstats" -o train -- python3 tools/train_bench.py > "$OUT/train_line_under_rocprof.json" 2> "$OUT/train_rocprof.err"
+cp "$(find "$OUT/tstats" -name '*kernel_stats.csv' | head -1)" "$OUT/train_kernel_stats.csv"
+rm -rf "$OUT/tstats"
+timeout -k 10 300 python tools/wgrad_bench.py > "$OUT/train_wgrad_per_shape.txt" 2>&1
 echo done
