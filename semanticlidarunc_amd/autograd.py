@@ -34,6 +34,38 @@ class LayerCfg:
         self.precision = precision          # forward conv products: "fp32" (exact MFMA) or "f16x3" (split-fp16, fp32 storage)
 
 
+# BatchNorm.num_batches_tracked += 1 is one tiny launch per layer (42 per SalsaNext step, 0.2 ms): inside a model call the increments are
+# collected and applied as ONE multi-tensor add when the outermost module call returns (salsanext._FusedBlock.__call__), i.e. before anything
+# outside the model can look at the buffers; outside any such call the increment is immediate.
+_NBT_DEPTH = 0
+_NBT_PENDING: list = []
+
+
+def bump_num_batches_tracked(bn) -> None:
+    if bn.num_batches_tracked is None:
+        return
+    if _NBT_DEPTH > 0:
+        _NBT_PENDING.append(bn.num_batches_tracked)
+    else:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+
+
+def nbt_scope_enter() -> None:
+    global _NBT_DEPTH
+    _NBT_DEPTH += 1
+
+
+def nbt_scope_exit() -> None:
+    global _NBT_DEPTH
+    _NBT_DEPTH -= 1
+    if _NBT_DEPTH == 0 and _NBT_PENDING:
+        pend = list(_NBT_PENDING)
+        _NBT_PENDING.clear()
+        with torch.no_grad():
+            torch._foreach_add_(pend, 1)
+
+
 class ConvLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: LayerCfg, weight, bias, gamma, beta, resid, *tensors):
@@ -41,7 +73,7 @@ class ConvLayerFn(torch.autograd.Function):
         bn: Optional[nn.BatchNorm2d] = cfg.bn
         train_stats = bn is not None and bool(bn.training)
         # train-mode BatchNorm: the exact-fp32 conv kernel adds the batch statistics of what it stores while it stores it
-        fused_stats = torch.zeros((2, cfg.cout), dtype=torch.float64, device=weight.device) if (_FUSE_STATS and train_stats and cfg.precision == "fp32") else None
+        fused_stats = ops.zeros_f64((2, cfg.cout), weight.device) if (_FUSE_STATS and train_stats and cfg.precision == "fp32") else None
         y = ops.conv2d_fused(srcs, cfg.wpack, cfg.cout, cfg.ksize, cfg.dil, cfg.pad,
                              bias=None if bias is None else bias.detach(), slope=cfg.slope, precision=cfg.precision, stats=fused_stats)
         mean = invstd = None
@@ -57,8 +89,7 @@ class ConvLayerFn(torch.autograd.Function):
                                                    bn.running_mean if (track or not train_stats) else None,
                                                    bn.running_var if (track or not train_stats) else None, train_stats)
             if track:
-                with torch.no_grad():
-                    bn.num_batches_tracked += 1
+                bump_num_batches_tracked(bn)
             z = ops.affine(y, a, b, None if resid is None else resid.detach().contiguous())
         elif resid is not None:
             z = ops.affine(y, None, None, resid.detach().contiguous())

@@ -21,6 +21,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
+from . import autograd as _autograd
 from . import h8, ops
 from .autograd import AvgPoolFn, ConvLayerFn, LayerCfg
 from .ops import ConvSource
@@ -88,6 +89,14 @@ def _tkey(*ts):
 
 class _FusedBlock(nn.Module):
     """Shared machinery: run ``conv -> LeakyReLU -> BatchNorm(eval) [-> + resid]`` as one launch."""
+
+    def __call__(self, *args, **kwargs):
+        # train-mode BatchNorm bookkeeping of all layers inside the outermost call is flushed as one launch when it returns (autograd.py)
+        _autograd.nbt_scope_enter()
+        try:
+            return super().__call__(*args, **kwargs)
+        finally:
+            _autograd.nbt_scope_exit()
 
     def _folded_bn(self, p: _Prepared, bn: Optional[nn.BatchNorm2d]):
         if bn is None:
