@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -136,6 +136,8 @@ SIGNATURES = {
     "slu_conv2d_wgrad": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    c_f32p, c_f32p, c_stream]),
     "slu_conv1x1_wgrad_nchw": (C.c_int, [c_f32p, C.POINTER(ConvSrc), C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "slu_conv2d_wgrad_nchw": (C.c_int, [c_f32p, C.POINTER(ConvSrc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
+                                        c_stream]),
     "slu_maxpool3s2_fwd": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_nearest_down": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_space_to_depth2": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),

@@ -21,6 +21,7 @@ from .ops import ConvSource
 # train-mode BatchNorm statistics accumulated by the conv kernel itself instead of a second pass over its output (A/B switch; -1.2 ms of a
 # 37.6 ms step.  A fused "da in both layouts" gradient pass was also built and measured: slower than the two launches, not kept)
 _FUSE_STATS = os.environ.get("SLU_TRAIN_FUSE", "1") != "0"
+_WGRAD_NCHW = os.environ.get("SLU_WGRAD_NCHW", "1") != "0"      # A/B: 0 = weight gradients from channel-last copies
 
 
 class LayerCfg:
@@ -129,8 +130,10 @@ class ConvLayerFn(torch.autograd.Function):
         cin = weight.shape[1]
         dweight = None
         if need[1]:
-            if cfg.ksize == 1:      # 1x1: straight from the NCHW tensors when the sources are plain and 32-aligned (all of SalsaNext's are)
-                dweight = ops.conv1x1_wgrad_nchw(da, srcs)
+            # straight from the NCHW tensors when the sources are plain and 32-aligned (all of SalsaNext's layers but UpBlock.conv1, whose
+            # inputs carry PixelShuffle / dropout multipliers): no channel-last copies of da and of the concatenated input
+            if _WGRAD_NCHW:
+                dweight = ops.conv1x1_wgrad_nchw(da, srcs) if cfg.ksize == 1 else ops.conv2d_wgrad_nchw(da, srcs, cfg.ksize, cfg.dil, cfg.pad)
             if dweight is None:
                 dweight = ops.conv2d_wgrad(ops.nchw_to_nhwc(da), ops.gather_nhwc(srcs), n, h, w, cfg.cout, cin, cfg.ksize, cfg.dil, cfg.pad)
         dsrc: List[Optional[torch.Tensor]] = [None] * nsrc

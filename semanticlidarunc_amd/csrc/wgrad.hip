@@ -320,6 +320,125 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_nchw_kernel(const W1Args a) {
     }
 }
 
+// k x k convs straight from the NCHW tensors.  Lane (channel jj, half hh) owns 8 consecutive pixels of one row per unit of 16: the A operand
+// is two 16-byte loads of da, the B operands of ALL taps come from one window of 8 + L + R input pixels per tap row (two 16-byte loads + the L
+// pixels before and the R after), so a unit costs 2 + KS * 4 load instructions for 8 * KS * KS MFMAs (the channel-last form: 1 + KS * KS
+// four-byte loads per KS * KS MFMAs), and neither da nor the inputs are copied to channel-last first.  The K pairing (pixel e of half 0 with
+// pixel e of half 1) is the same on both operands.  Zero padding: rows outside the image contribute zeros (wave-uniform), the pixels before /
+// after a row are zeroed at the row's ends (units never straddle rows: W % 16 == 0).  Sources of a concatenated input are per-32-channel-block
+// base pointers (as in wgrad1x1_nchw_kernel).  Partial sums leave through the same LDS reduction + atomics into the tap-major image dWp.
+struct WkArgs {
+  const float* da;               // [N][Cout][H][W]
+  const float* src[SLU_MAX_SRC]; // [N][Cs][H][W]
+  int cs[SLU_MAX_SRC], cbeg[SLU_MAX_SRC];
+  int nsrc, N, H, W, Cout, Cin, Cip;
+  float* dWp;                    // [Cout][T][Cip], zeroed
+};
+
+template <int KS, int DIL, int PAD>
+__global__ __launch_bounds__(256, 2) void wgradk_nchw_kernel(const WkArgs a) {
+  constexpr int T = KS * KS, L = PAD, R = (KS - 1) * DIL - PAD, WIN = 8 + L + R;
+  static_assert(L >= 1 && L <= 2 && R >= 1 && R <= 2, "window edges are one or two pixels");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hh = lane >> 5, jj = lane & 31;
+  const int cob = blockIdx.y, cib = blockIdx.z;
+  const long long HW = (long long)a.H * a.W;
+  const int upr = a.W / 16;                                  // units per row
+  const long long nunits = (long long)a.N * a.H * upr;
+  constexpr int RUN = 4;                                     // consecutive units per visit: 64 pixels of a row
+  const long long nruns = (nunits + RUN - 1) / RUN;
+  const long long worker = (long long)blockIdx.x * 4 + wave, nworkers = (long long)gridDim.x * 4;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  // lanes past the last channel read channel 0: their rows / columns of the product are never stored
+  const int co = cob * 32 + jj, ci = cib * 32 + jj;
+  const float* abase = a.da + (size_t)(co < a.Cout ? co : 0) * HW + 8 * hh;
+  int s = 0;
+#pragma unroll
+  for (int t = 1; t < SLU_MAX_SRC; ++t)
+    if (t < a.nsrc && ci >= a.cbeg[t]) s = t;
+  const float* bbase = a.src[s] + (size_t)(ci < a.Cin ? ci - a.cbeg[s] : 0) * HW + 8 * hh;
+  const long long aimg = (long long)a.Cout * HW, bimg = (long long)a.cs[s] * HW;
+
+  for (long long run = worker; run < nruns; run += nworkers) {
+    const long long u0 = run * RUN;
+    const long long u1 = (u0 + RUN < nunits) ? u0 + RUN : nunits;
+    for (long long u = u0; u < u1; ++u) {
+      const long long row = u / upr;                         // n * H + y
+      const int xu = (int)(u - row * upr);
+      const int n = (int)(row / a.H), y = (int)(row - (long long)n * a.H);
+      const int x0 = xu * 16 + 8 * hh;
+      const float* pa = abase + (size_t)n * aimg + (size_t)y * a.W + xu * 16;
+      const float4 a0 = *reinterpret_cast<const float4*>(pa), a1 = *reinterpret_cast<const float4*>(pa + 4);
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      float win[KS][WIN];
+#pragma unroll
+      for (int ti = 0; ti < KS; ++ti) {
+        const int yy = y - PAD + ti * DIL;
+        if (yy >= 0 && yy < a.H) {                           // wave-uniform
+          const float* pb = bbase + (size_t)n * bimg + (size_t)yy * a.W + xu * 16;
+          const float4 b0 = *reinterpret_cast<const float4*>(pb), b1 = *reinterpret_cast<const float4*>(pb + 4);
+          const bool lok = x0 > 0, rok = x0 + 8 < a.W;       // the pixels before / after this lane's 8 exist in the row
+          float lft[2], rgt[2];
+          if constexpr (L == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(lok ? pb - 2 : pb);
+            lft[0] = lok ? v.x : 0.0f; lft[1] = lok ? v.y : 0.0f;
+          } else {
+            const float v = *(lok ? pb - 1 : pb);
+            lft[0] = lok ? v : 0.0f; lft[1] = 0.0f;
+          }
+          if constexpr (R == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(rok ? pb + 8 : pb);
+            rgt[0] = rok ? v.x : 0.0f; rgt[1] = rok ? v.y : 0.0f;
+          } else {
+            const float v = *(rok ? pb + 8 : pb);
+            rgt[0] = rok ? v : 0.0f; rgt[1] = 0.0f;
+          }
+#pragma unroll
+          for (int j = 0; j < L; ++j) win[ti][j] = lft[j];
+          win[ti][L + 0] = b0.x; win[ti][L + 1] = b0.y; win[ti][L + 2] = b0.z; win[ti][L + 3] = b0.w;
+          win[ti][L + 4] = b1.x; win[ti][L + 5] = b1.y; win[ti][L + 6] = b1.z; win[ti][L + 7] = b1.w;
+#pragma unroll
+          for (int j = 0; j < R; ++j) win[ti][L + 8 + j] = rgt[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < WIN; ++j) win[ti][j] = 0.0f;
+        }
+      }
+      // output pixel e with tap (ti, tj) reads input pixel x0 + e - PAD + tj * DIL = window index e + tj * DIL
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int ti = 0; ti < KS; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < KS; ++tj)
+            acc[ti * KS + tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], win[ti][e + tj * DIL], acc[ti * KS + tj], 0, 0, 0);
+    }
+  }
+
+  __shared__ float s_red[4][16][64];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[t][r];
+    __syncthreads();
+    if (wave == (t & 3)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = (s_red[0][r][lane] + s_red[1][r][lane]) + (s_red[2][r][lane] + s_red[3][r][lane]);
+        const int c = cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (c < a.Cout) atomicAdd(&a.dWp[((size_t)c * T + t) * a.Cip + cib * 32 + jj], v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void wgrad_unpack_kernel(const float* __restrict__ dWp, int Cout, int Cin, int T, int Cip, float* __restrict__ dW, size_t total) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int t = (int)(e % T);
@@ -393,7 +512,48 @@ int launch_w1_nchw_t(const W1Args& a, hipStream_t st) {
   SLU_CHECK_LAUNCH();
 }
 
+template <int KS, int DIL, int PAD>
+int launch_wk_nchw(const WkArgs& a, hipStream_t st) {
+  const int ncob = (a.Cout + 31) / 32, ncib = a.Cip / 32;
+  const long long nruns = ((long long)a.N * a.H * (a.W / 16) + 3) / 4;
+  long long gx = 512 / ((long long)ncob * ncib);            // two resident workgroups per CU over all channel-block pairs
+  if (gx < 1) gx = 1;
+  if (gx * 4 > nruns) gx = (nruns + 3) / 4;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((wgradk_nchw_kernel<KS, DIL, PAD>), dim3((unsigned)gx, ncob, ncib), dim3(256), 0, st, a);
+  SLU_CHECK_LAUNCH();
+}
+
 }  // namespace
+
+extern "C" int slu_conv2d_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int H, int W, int Cout, int ksize, int dil, int pad,
+                                     float* dWp, float* dW, slu_stream_t stream) {
+  if (!da || !src || !dWp || !dW || nsrc < 1 || nsrc > SLU_MAX_SRC || N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SLU_EINVAL;
+  if (W % 16 || ((uintptr_t)da & 15) || Cout > 65535 * 32) return SLU_EUNSUPPORTED;
+  WkArgs a{};
+  int c = 0;
+  for (int s = 0; s < nsrc; ++s) {
+    if (!src[s].ptr || src[s].C <= 0) return SLU_EINVAL;
+    if (src[s].pixel_shuffle || src[s].scale || src[s].nbatch || src[s].cuse || ((uintptr_t)src[s].ptr & 15)) return SLU_EUNSUPPORTED;
+    if (s + 1 < nsrc && (src[s].C % 32)) return SLU_EUNSUPPORTED;          // a 32-channel block must not straddle two tensors
+    a.src[s] = src[s].ptr; a.cs[s] = src[s].C; a.cbeg[s] = c;
+    c += src[s].C;
+  }
+  if (c > 65535 * 32) return SLU_EUNSUPPORTED;
+  a.da = da; a.nsrc = nsrc; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.Cin = c; a.Cip = (c + 31) / 32 * 32; a.dWp = dWp;
+  hipStream_t st = slu_stream(stream);
+  if (hipMemsetAsync(dWp, 0, slu_wgrad_packed_floats(Cout, c, ksize) * sizeof(float), st) != hipSuccess) return SLU_ELAUNCH;
+  int rc;
+  if (ksize == 3 && dil == 1 && pad == 1) rc = launch_wk_nchw<3, 1, 1>(a, st);
+  else if (ksize == 3 && dil == 2 && pad == 2) rc = launch_wk_nchw<3, 2, 2>(a, st);
+  else if (ksize == 2 && dil == 2 && pad == 1) rc = launch_wk_nchw<2, 2, 1>(a, st);
+  else return SLU_EUNSUPPORTED;
+  if (rc != SLU_OK) return rc;
+  const size_t total = (size_t)Cout * c * ksize * ksize;
+  const unsigned g = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(g), dim3(256), 0, st, dWp, Cout, c, ksize * ksize, a.Cip, dW, total);
+  SLU_CHECK_LAUNCH();
+}
 
 extern "C" int slu_conv1x1_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int HW, int Cout, float* dW, slu_stream_t stream) {
   if (!da || !src || !dW || nsrc < 1 || nsrc > SLU_MAX_SRC || N <= 0 || HW <= 0 || Cout <= 0) return SLU_EINVAL;

@@ -110,6 +110,27 @@ def test_wgrad_1x1_from_nchw(cuda, chans, cout, n, h, w):
     assert ops.conv1x1_wgrad_nchw(torch.zeros(1, 32, 4, 8, device=cuda), [ConvSource(torch.zeros(1, 32, 4, 8, device=cuda), torch.ones(1, 32, device=cuda))]) is None
 
 
+@pytest.mark.parametrize("fam", [(3, 1, 1), (3, 2, 2), (2, 2, 1)])
+@pytest.mark.parametrize("chans,cout,n,h,w", [((32,), 32, 2, 8, 32), ((5,), 32, 1, 5, 16), ((32, 48), 40, 2, 7, 48), ((64, 64, 32), 64, 3, 4, 16), ((128,), 128, 2, 16, 64)])
+def test_wgrad_kxk_from_nchw(cuda, fam, chans, cout, n, h, w):
+    """3x3 (dil 1 / 2) and 2x2-dilated weight gradients read straight from NCHW da and the (concatenated) sources == autograd of F.conv2d on the
+    CPU (1e-4 of the gradient's scale: fp32 MFMA sums in another order, fp32 atomics): one-unit rows (both row ends in one unit), image borders
+    in y, channel counts that are not multiples of 32; uncovered shapes return None (then the channel-last kernel runs)."""
+    k, dil, pad = fam
+    g = torch.Generator().manual_seed(sum(chans) + cout + k + dil)
+    xs = [torch.randn(n, c, h, w, generator=g) for c in chans]
+    wt = (torch.randn(cout, sum(chans), k, k, generator=g) / (sum(chans) * k * k) ** 0.5).requires_grad_(True)
+    da = torch.randn(n, cout, h, w, generator=g)
+    F.conv2d(torch.cat(xs, 1), wt, None, padding=pad, dilation=dil).backward(da)
+    dw = ops.conv2d_wgrad_nchw(da.to(cuda), [ConvSource(x.to(cuda)) for x in xs], k, dil, pad)
+    assert dw is not None and _rel(dw.cpu(), wt.grad) <= 1e-4
+    z = lambda *sh: torch.zeros(*sh, device=cuda)
+    assert ops.conv2d_wgrad_nchw(z(1, 32, 4, 24), [ConvSource(z(1, 32, 4, 24))], k, dil, pad) is None                  # W % 16
+    assert ops.conv2d_wgrad_nchw(z(1, 32, 4, 16), [ConvSource(z(1, 32, 4, 16), torch.ones(1, 32, device=cuda))], k, dil, pad) is None
+    assert ops.conv2d_wgrad_nchw(z(1, 32, 4, 16), [ConvSource(z(1, 5, 4, 16)), ConvSource(z(1, 32, 4, 16))], k, dil, pad) is None
+    assert ops.conv2d_wgrad_nchw(z(1, 32, 4, 16), [ConvSource(z(1, 32, 4, 16))], 3, 3, 3) is None
+
+
 def _layer_oracle(srcs, w, b, gamma, beta, resid, pad, dil, train, rm, rv):
     y = osalsa.fused_conv(srcs, w, b, pad, dil, 0.01)
     if train:

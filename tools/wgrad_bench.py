@@ -63,3 +63,31 @@ for chans, cout, h, w in [((5,), 32, 64, 2048), ((64, 64, 64), 64, 64, 2048), ((
         res.append(e0.elapsed_time(e1) / 5 * 1e3)
     gb = 4.0 * b * h * w * (cin + cout) / 1e3
     print(f"1x1 {cin:4d}->{cout:3d} {h:3d}x{w:4d}  channel-last copies + kernel {res[0]:8.1f} us   from NCHW {res[1]:8.1f} us ({gb / res[1]:6.0f} GB/s of its inputs)", flush=True)
+
+# the 3x3 / 2x2-dilated layers straight from NCHW (slu_conv2d_wgrad_nchw) against channel-last copies + the kernel above
+for cin, cout, k, dil, pad, h, w in [(32, 32, 3, 1, 1, 64, 2048), (32, 64, 3, 1, 1, 64, 2048), (64, 64, 3, 2, 2, 64, 2048), (64, 64, 2, 2, 1, 64, 2048),
+                                     (128, 128, 3, 2, 2, 32, 1024), (128, 128, 2, 2, 1, 32, 1024), (256, 256, 3, 2, 2, 16, 512), (256, 256, 3, 1, 1, 8, 256)]:
+    da = torch.randn(b, cout, h, w, device=dev)
+    xs = [ConvSource(torch.randn(b, cin, h, w, device=dev))]
+
+    def old():
+        return ops.conv2d_wgrad(ops.nchw_to_nhwc(da), ops.gather_nhwc(xs), b, h, w, cout, cin, k, dil, pad)
+
+    def new():
+        return ops.conv2d_wgrad_nchw(da, xs, k, dil, pad)
+
+    res = []
+    for fn in (old, new):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 5 * 1e3)
+    fl = 2.0 * cin * cout * k * k * b * h * w
+    print(f"k{k}d{dil} {cin:4d}->{cout:3d} {h:3d}x{w:4d}  channel-last copies + kernel {res[0]:8.1f} us   from NCHW {res[1]:8.1f} us "
+          f"({fl / res[1] / 1e6 / 157.3 * 100:5.1f} % of the fp32 MFMA peak)", flush=True)
