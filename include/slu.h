@@ -233,7 +233,8 @@ int slu_conv2d_wgrad(const float* da_t, const float* in_t, int N, int H, int W, 
  * slu_conv2d_fwd (plain tensors only: no PixelShuffle / multiplier / broadcast; every source but the last a multiple of 32 channels; HW a
  * multiple of 32; 16-byte aligned bases) -> dW [Cout, sum of source channels].  SLU_EUNSUPPORTED otherwise (use slu_conv2d_wgrad). */
 int slu_conv1x1_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int HW, int Cout, float* dW, slu_stream_t stream);
-/* the same for the 3x3 (dil 1 / 2, pad = dil) and 2x2 (dil 2, pad 1) families: da [N,Cout,H,W], plain sources as above, W a multiple of 16;
+/* the 3x3 (dil 1 / 2, pad = dil) and 2x2 (dil 2, pad 1) families: da [N,Cout,H,W]; sources as in slu_conv2d_fwd including PixelShuffle and
+ * multipliers (no broadcast / channel cut), any channel counts; W a multiple of 16 (PixelShuffle sources: H even);
  * dWp: scratch of slu_wgrad_packed_floats floats -> dW [Cout, Cin, k, k].  SLU_EUNSUPPORTED otherwise (use slu_conv2d_wgrad). */
 int slu_conv2d_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int H, int W, int Cout, int ksize, int dil, int pad,
                           float* dWp, float* dW, slu_stream_t stream);

@@ -329,8 +329,9 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_nchw_kernel(const W1Args a) {
 // base pointers (as in wgrad1x1_nchw_kernel).  Partial sums leave through the same LDS reduction + atomics into the tap-major image dWp.
 struct WkArgs {
   const float* da;               // [N][Cout][H][W]
-  const float* src[SLU_MAX_SRC]; // [N][Cs][H][W]
-  int cs[SLU_MAX_SRC], cbeg[SLU_MAX_SRC];
+  const float* src[SLU_MAX_SRC]; // [N][Cs][H][W], or (PixelShuffle) [N][Cs][H/2][W/2] contributing Cs/4 channels
+  const float* scale[SLU_MAX_SRC];   // [N][Cs] multiplier per stored channel, or nullptr
+  int cs[SLU_MAX_SRC], cbeg[SLU_MAX_SRC], ps[SLU_MAX_SRC];
   int nsrc, N, H, W, Cout, Cin, Cip;
   float* dWp;                    // [Cout][T][Cip], zeroed
 };
@@ -358,12 +359,19 @@ __global__ __launch_bounds__(256, 2) void wgradk_nchw_kernel(const WkArgs a) {
   // lanes past the last channel read channel 0: their rows / columns of the product are never stored
   const int co = cob * 32 + jj, ci = cib * 32 + jj;
   const float* abase = a.da + (size_t)(co < a.Cout ? co : 0) * HW + 8 * hh;
-  int s = 0;
+  int s = 0;                                                 // per lane: a 32-channel block may straddle two sources
 #pragma unroll
   for (int t = 1; t < SLU_MAX_SRC; ++t)
     if (t < a.nsrc && ci >= a.cbeg[t]) s = t;
-  const float* bbase = a.src[s] + (size_t)(ci < a.Cin ? ci - a.cbeg[s] : 0) * HW + 8 * hh;
-  const long long aimg = (long long)a.Cout * HW, bimg = (long long)a.cs[s] * HW;
+  const int cl = ci < a.Cin ? ci - a.cbeg[s] : 0;            // channel inside the source (of the shuffled tensor for a PixelShuffle source)
+  const bool lps = a.ps[s] != 0;
+  const float* sbase = a.src[s];
+  const float* bbase = sbase + (size_t)cl * HW + 8 * hh;     // plain sources
+  const float* scl = a.scale[s];
+  const int csrc = a.cs[s];
+  const long long aimg = (long long)a.Cout * HW, bimg = (long long)csrc * HW;
+  const int W2 = a.W >> 1;
+  const long long HW4 = HW >> 2, bimg4 = (long long)csrc * HW4;
 
   for (long long run = worker; run < nruns; run += nworkers) {
     const long long u0 = run * RUN;
@@ -381,28 +389,49 @@ __global__ __launch_bounds__(256, 2) void wgradk_nchw_kernel(const WkArgs a) {
       for (int ti = 0; ti < KS; ++ti) {
         const int yy = y - PAD + ti * DIL;
         if (yy >= 0 && yy < a.H) {                           // wave-uniform
-          const float* pb = bbase + (size_t)n * bimg + (size_t)yy * a.W + xu * 16;
-          const float4 b0 = *reinterpret_cast<const float4*>(pb), b1 = *reinterpret_cast<const float4*>(pb + 4);
           const bool lok = x0 > 0, rok = x0 + 8 < a.W;       // the pixels before / after this lane's 8 exist in the row
-          float lft[2], rgt[2];
-          if constexpr (L == 2) {
-            const float2 v = *reinterpret_cast<const float2*>(lok ? pb - 2 : pb);
-            lft[0] = lok ? v.x : 0.0f; lft[1] = lok ? v.y : 0.0f;
+          float own[8], lft[2] = {0.0f, 0.0f}, rgt[2] = {0.0f, 0.0f};
+          if (!lps) {
+            const float* pb = bbase + (size_t)n * bimg + (size_t)yy * a.W + xu * 16;
+            const float4 b0 = *reinterpret_cast<const float4*>(pb), b1 = *reinterpret_cast<const float4*>(pb + 4);
+            const float sc = scl ? scl[(size_t)n * csrc + cl] : 1.0f;
+            own[0] = b0.x * sc; own[1] = b0.y * sc; own[2] = b0.z * sc; own[3] = b0.w * sc;
+            own[4] = b1.x * sc; own[5] = b1.y * sc; own[6] = b1.z * sc; own[7] = b1.w * sc;
+            if constexpr (L == 2) {
+              const float2 v = *reinterpret_cast<const float2*>(lok ? pb - 2 : pb);
+              lft[0] = lok ? v.x * sc : 0.0f; lft[1] = lok ? v.y * sc : 0.0f;
+            } else {
+              const float v = *(lok ? pb - 1 : pb);
+              lft[0] = lok ? v * sc : 0.0f;
+            }
+            if constexpr (R == 2) {
+              const float2 v = *reinterpret_cast<const float2*>(rok ? pb + 8 : pb);
+              rgt[0] = rok ? v.x * sc : 0.0f; rgt[1] = rok ? v.y * sc : 0.0f;
+            } else {
+              const float v = *(rok ? pb + 8 : pb);
+              rgt[0] = rok ? v * sc : 0.0f;
+            }
           } else {
-            const float v = *(lok ? pb - 1 : pb);
-            lft[0] = lok ? v : 0.0f; lft[1] = 0.0f;
-          }
-          if constexpr (R == 2) {
-            const float2 v = *reinterpret_cast<const float2*>(rok ? pb + 8 : pb);
-            rgt[0] = rok ? v.x : 0.0f; rgt[1] = rok ? v.y : 0.0f;
-          } else {
-            const float v = *(rok ? pb + 8 : pb);
-            rgt[0] = rok ? v : 0.0f; rgt[1] = 0.0f;
+            // PixelShuffle(2): in[c][yy][x] = stored[4 c + 2 (yy & 1) + (x & 1)][yy / 2][x / 2]: the 8 pixels interleave 4 half-resolution
+            // pixels of two stored channels; the multiplier is per STORED channel
+            const int c0 = 4 * cl + 2 * (yy & 1);
+            const float* p0 = sbase + (size_t)n * bimg4 + (size_t)c0 * HW4 + (size_t)(yy >> 1) * W2 + (x0 >> 1);
+            const float* p1 = p0 + HW4;
+            const float4 e0 = *reinterpret_cast<const float4*>(p0), e1 = *reinterpret_cast<const float4*>(p1);
+            const float s0 = scl ? scl[(size_t)n * csrc + c0] : 1.0f, s1 = scl ? scl[(size_t)n * csrc + c0 + 1] : 1.0f;
+            own[0] = e0.x * s0; own[1] = e1.x * s1; own[2] = e0.y * s0; own[3] = e1.y * s1;
+            own[4] = e0.z * s0; own[5] = e1.z * s1; own[6] = e0.w * s0; own[7] = e1.w * s1;
+            const float l0 = *(lok ? p0 - 1 : p0), l1 = *(lok ? p1 - 1 : p1);       // pixels x0 - 2 (even) and x0 - 1 (odd)
+            const float r0 = *(rok ? p0 + 4 : p0), r1 = *(rok ? p1 + 4 : p1);       // pixels x0 + 8 (even) and x0 + 9 (odd)
+            if constexpr (L == 2) { lft[0] = lok ? l0 * s0 : 0.0f; lft[1] = lok ? l1 * s1 : 0.0f; }
+            else lft[0] = lok ? l1 * s1 : 0.0f;
+            rgt[0] = rok ? r0 * s0 : 0.0f;
+            if constexpr (R == 2) rgt[1] = rok ? r1 * s1 : 0.0f;
           }
 #pragma unroll
           for (int j = 0; j < L; ++j) win[ti][j] = lft[j];
-          win[ti][L + 0] = b0.x; win[ti][L + 1] = b0.y; win[ti][L + 2] = b0.z; win[ti][L + 3] = b0.w;
-          win[ti][L + 4] = b1.x; win[ti][L + 5] = b1.y; win[ti][L + 6] = b1.z; win[ti][L + 7] = b1.w;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) win[ti][L + j] = own[j];
 #pragma unroll
           for (int j = 0; j < R; ++j) win[ti][L + 8 + j] = rgt[j];
         } else {
@@ -534,10 +563,10 @@ extern "C" int slu_conv2d_wgrad_nchw(const float* da, const slu_conv_src* src, i
   int c = 0;
   for (int s = 0; s < nsrc; ++s) {
     if (!src[s].ptr || src[s].C <= 0) return SLU_EINVAL;
-    if (src[s].pixel_shuffle || src[s].scale || src[s].nbatch || src[s].cuse || ((uintptr_t)src[s].ptr & 15)) return SLU_EUNSUPPORTED;
-    if (s + 1 < nsrc && (src[s].C % 32)) return SLU_EUNSUPPORTED;          // a 32-channel block must not straddle two tensors
-    a.src[s] = src[s].ptr; a.cs[s] = src[s].C; a.cbeg[s] = c;
-    c += src[s].C;
+    if (src[s].nbatch || src[s].cuse || ((uintptr_t)src[s].ptr & 15)) return SLU_EUNSUPPORTED;
+    if (src[s].pixel_shuffle && ((src[s].C & 3) || (H & 1))) return SLU_EINVAL;
+    a.src[s] = src[s].ptr; a.scale[s] = src[s].scale; a.cs[s] = src[s].C; a.cbeg[s] = c; a.ps[s] = src[s].pixel_shuffle ? 1 : 0;
+    c += src[s].pixel_shuffle ? src[s].C / 4 : src[s].C;
   }
   if (c > 65535 * 32) return SLU_EUNSUPPORTED;
   a.da = da; a.nsrc = nsrc; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.Cin = c; a.Cip = (c + 31) / 32 * 32; a.dWp = dWp;

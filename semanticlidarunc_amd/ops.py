@@ -623,19 +623,18 @@ def conv2d_wgrad(da_t, in_t, n, h, w, cout, cin, ksize, dil, pad):
 
 
 def conv2d_wgrad_nchw(da: torch.Tensor, srcs: Sequence[ConvSource], ksize: int, dil: int, pad: int):
-    """dW [Cout, Cin, k, k] of a 3x3 (dil 1 / 2) or 2x2-dilated conv straight from NCHW da and its plain sources, or None when the shape is
-    not covered (then: conv2d_wgrad on channel-last copies)."""
+    """dW [Cout, Cin, k, k] of a 3x3 (dil 1 / 2) or 2x2-dilated conv straight from NCHW da and its sources (PixelShuffle and multipliers
+    included), or None when the shape is not covered (then: conv2d_wgrad on channel-last copies)."""
     _req(da, "da")
     n, cout, h, w = da.shape
     if (ksize, dil, pad) not in ((3, 1, 1), (3, 2, 2), (2, 2, 1)) or w % 16:
         return None
-    if any(s.pixel_shuffle or s.scale is not None or s.nbatch or s.cuse for s in srcs):
-        return None
-    if any(s.tensor.shape[1] % 32 for s in srcs[:-1]) or any(tuple(s.tensor.shape[2:]) != (h, w) or s.tensor.shape[0] != n for s in srcs):
+    if any(s.nbatch or s.cuse for s in srcs) or (h % 2 and any(s.pixel_shuffle for s in srcs)):
         return None
     arr = (_lib.ConvSrc * _lib.MAX_SRC)()
-    _fill_srcs(arr, srcs)
-    cin = sum(s.tensor.shape[1] for s in srcs)
+    if _fill_srcs(arr, srcs) != (n, h, w):
+        raise RuntimeError("conv2d_wgrad_nchw: da and the sources disagree on (N, H, W)")
+    cin = sum(s.tensor.shape[1] // 4 if s.pixel_shuffle else s.tensor.shape[1] for s in srcs)
     lib = _lib.load()
     scratch = torch.empty(lib.slu_wgrad_packed_floats(cout, cin, ksize), dtype=torch.float32, device=da.device)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=da.device)

@@ -126,9 +126,17 @@ def test_wgrad_kxk_from_nchw(cuda, fam, chans, cout, n, h, w):
     assert dw is not None and _rel(dw.cpu(), wt.grad) <= 1e-4
     z = lambda *sh: torch.zeros(*sh, device=cuda)
     assert ops.conv2d_wgrad_nchw(z(1, 32, 4, 24), [ConvSource(z(1, 32, 4, 24))], k, dil, pad) is None                  # W % 16
-    assert ops.conv2d_wgrad_nchw(z(1, 32, 4, 16), [ConvSource(z(1, 32, 4, 16), torch.ones(1, 32, device=cuda))], k, dil, pad) is None
-    assert ops.conv2d_wgrad_nchw(z(1, 32, 4, 16), [ConvSource(z(1, 5, 4, 16)), ConvSource(z(1, 32, 4, 16))], k, dil, pad) is None
-    assert ops.conv2d_wgrad_nchw(z(1, 32, 4, 16), [ConvSource(z(1, 32, 4, 16))], 3, 3, 3) is None
+    assert ops.conv2d_wgrad_nchw(z(1, 32, 4, 16), [ConvSource(z(1, 32, 4, 16))], 3, 3, 3) is None                      # not one of the families
+    # UpBlock.conv1: PixelShuffle(x) with a per-stored-channel multiplier | skip with a multiplier, block boundaries inside a 32-channel block
+    cx, cs = 4 * (chans[0] // 4 + 1), 24
+    xs2 = [torch.randn(n, cx, h // 2 if h % 2 == 0 else h, w // 2, generator=g), torch.randn(n, cs, h, w, generator=g)]
+    if h % 2 == 0:
+        sc = [(torch.rand(n, cx, generator=g) > 0.3).float() * 1.25, (torch.rand(n, cs, generator=g) > 0.3).float() * 1.25]
+        cat = torch.cat([F.pixel_shuffle(xs2[0] * sc[0][:, :, None, None], 2), xs2[1] * sc[1][:, :, None, None]], 1)
+        w2 = (torch.randn(cout, cx // 4 + cs, k, k, generator=g) / ((cx // 4 + cs) * k * k) ** 0.5).requires_grad_(True)
+        F.conv2d(cat, w2, None, padding=pad, dilation=dil).backward(da)
+        dw2 = ops.conv2d_wgrad_nchw(da.to(cuda), [ConvSource(xs2[0].to(cuda), sc[0].to(cuda), True), ConvSource(xs2[1].to(cuda), sc[1].to(cuda))], k, dil, pad)
+        assert dw2 is not None and _rel(dw2.cpu(), w2.grad) <= 1e-4
 
 
 def _layer_oracle(srcs, w, b, gamma, beta, resid, pad, dil, train, rm, rv):

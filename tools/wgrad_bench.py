@@ -91,3 +91,25 @@ for cin, cout, k, dil, pad, h, w in [(32, 32, 3, 1, 1, 64, 2048), (32, 64, 3, 1,
     fl = 2.0 * cin * cout * k * k * b * h * w
     print(f"k{k}d{dil} {cin:4d}->{cout:3d} {h:3d}x{w:4d}  channel-last copies + kernel {res[0]:8.1f} us   from NCHW {res[1]:8.1f} us "
           f"({fl / res[1] / 1e6 / 157.3 * 100:5.1f} % of the fp32 MFMA peak)", flush=True)
+
+# UpBlock.conv1: PixelShuffle(x) with a multiplier | skip with a multiplier
+for cx, cs, cout, h, w in [(64, 64, 32, 64, 2048), (128, 128, 64, 32, 1024), (128, 256, 128, 16, 512), (256, 256, 128, 8, 256)]:
+    cin = cx // 4 + cs
+    da = torch.randn(b, cout, h, w, device=dev)
+    xs = [ConvSource(torch.randn(b, cx, h // 2, w // 2, device=dev), torch.ones(b, cx, device=dev) * 1.25, True),
+          ConvSource(torch.randn(b, cs, h, w, device=dev), torch.ones(b, cs, device=dev) * 1.25)]
+    res = []
+    for fn in (lambda: ops.conv2d_wgrad(ops.nchw_to_nhwc(da), ops.gather_nhwc(xs), b, h, w, cout, cin, 3, 1, 1), lambda: ops.conv2d_wgrad_nchw(da, xs, 3, 1, 1)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 5 * 1e3)
+    fl = 2.0 * cin * cout * 9 * b * h * w
+    print(f"k3d1 PixelShuffle({cx}) | {cs} -> {cout} {h:3d}x{w:4d}  channel-last copies + kernel {res[0]:8.1f} us   from NCHW {res[1]:8.1f} us "
+          f"({fl / res[1] / 1e6 / 157.3 * 100:5.1f} % of the fp32 MFMA peak)", flush=True)
