@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 23
+#define SLU_ABI_VERSION 24
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -99,6 +99,18 @@ int slu_conv_ck(int ksize);
 size_t slu_packed_weight_floats(int cout, int cin, int ksize, int ck);
 /* w: [cout, cin, ksize, ksize] (torch OIHW) -> out: packed image.  Re-run after every weight update. */
 int slu_pack_conv_weight(const float* w, int cout, int cin, int ksize, int ck, float* out, slu_stream_t stream);
+/* many weights in one launch (a training step repacks all of them after the optimizer step).  jobs_dev: DEVICE array; job i packs w
+ * [cout][cin][k][k] into `out` (slu_packed_weight_floats(cout, cin, k, ck) floats) as slu_pack_conv_weight does, or -- dgrad = 1 -- the weights
+ * of the data-gradient conv (slu_dgrad_weight + slu_pack_conv_weight: slu_packed_weight_floats(cin, cout, k, ck) floats); begin = sum of the
+ * output sizes of the jobs before it (ascending), total = sum over all jobs. */
+typedef struct slu_pack_job {
+  const float* w;
+  float* out;
+  int32_t cout, cin, ksize, ck;
+  int32_t dgrad, reserved;
+  uint64_t begin;
+} slu_pack_job;
+int slu_pack_conv_weights_multi(const slu_pack_job* jobs_dev, int njobs, size_t total, slu_stream_t stream);
 int slu_conv2d_fwd(const slu_conv_desc* desc, slu_stream_t stream);
 /* split-fp16 weight image (bytes) and its packer (w: [cout,cin,k,k] fp32 OIHW) */
 size_t slu_packed_weight_bytes_f16x3(int cout, int cin, int ksize);

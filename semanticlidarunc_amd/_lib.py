@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -60,6 +60,11 @@ class ConvH8Desc(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32), ("ck", C.c_int32),
+                ("dgrad", C.c_int32), ("reserved", C.c_int32), ("begin", C.c_uint64)]
+
+
 class ConvTailH8Desc(C.Structure):
     _fields_ = [
         ("a1", C.c_void_p), ("a2", C.c_void_p),
@@ -95,6 +100,7 @@ SIGNATURES = {
     "slu_conv_ck": (C.c_int, [C.c_int]),
     "slu_packed_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "slu_pack_conv_weight": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "slu_pack_conv_weights_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, c_stream]),
     "slu_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), c_stream]),
     "slu_packed_weight_bytes_f16x3": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_pack_conv_weight_f16x3": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_stream]),

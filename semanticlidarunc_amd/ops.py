@@ -78,6 +78,44 @@ def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class WeightPackPlan:
+    """The forward AND data-gradient MFMA images of a list of conv weights, rebuilt by ONE launch (slu_pack_conv_weights_multi) into buffers
+    that keep their addresses: `fwd[i]` == pack_conv_weight(w_i), `dgrad[i]` == pack_conv_weight(dgrad_weight(w_i)).  The plan records the
+    weights' addresses; `matches(weights)` tells whether it still describes them (a parameter that was re-allocated needs a new plan)."""
+
+    def __init__(self, weights: Sequence[torch.Tensor]):
+        lib = _lib.load()
+        self.ptrs = [w.data_ptr() for w in weights]
+        self.fwd, self.dgrad = [], []
+        jobs = (_lib.PackJob * (2 * len(weights)))()
+        begin = 0
+        for i, w in enumerate(weights):
+            _req(w, f"weights[{i}]")
+            if w.dim() != 4 or w.shape[2] != w.shape[3]:
+                raise RuntimeError(f"weights[{i}]: expected [Cout,Cin,k,k], got {tuple(w.shape)}")
+            cout, cin, ks, _ = w.shape
+            ck = lib.slu_conv_ck(ks)
+            for d, (co, ci), store in ((0, (cout, cin), self.fwd), (1, (cin, cout), self.dgrad)):
+                n = lib.slu_packed_weight_floats(co, ci, ks, ck)
+                if n == 0:
+                    raise RuntimeError(f"weights[{i}]: unsupported shape {tuple(w.shape)}")
+                out = torch.empty(n, dtype=torch.float32, device=w.device)
+                store.append(out)
+                j = jobs[2 * i + d]
+                j.w, j.out, j.cout, j.cin, j.ksize, j.ck, j.dgrad, j.begin = w.data_ptr(), out.data_ptr(), cout, cin, ks, ck, d, begin
+                begin += n
+        self.total, self.njobs = begin, 2 * len(weights)
+        import ctypes
+        raw = bytes(ctypes.string_at(ctypes.addressof(jobs), ctypes.sizeof(jobs)))
+        self.jobs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(weights[0].device)
+
+    def matches(self, weights: Sequence[torch.Tensor]) -> bool:
+        return len(weights) == len(self.ptrs) and all(w.data_ptr() == p for w, p in zip(weights, self.ptrs))
+
+    def run(self) -> None:
+        check(_lib.load().slu_pack_conv_weights_multi(self.jobs.data_ptr(), self.njobs, self.total, _stream()), "slu_pack_conv_weights_multi")
+
+
 def pack_conv_weight_f16x3(weight: torch.Tensor) -> torch.Tensor:
     """OIHW fp32 weight -> split-fp16 (hi, lo) MFMA A-fragment image for precision='f16x3'."""
     _req(weight, "weight")

@@ -46,6 +46,7 @@ _FUSE_TAIL_MAX_C = int(os.environ.get("SLU_FUSE_TAIL_MAX_C", "64"))
 # half-precision inference: a ResContextBlock (1x1 -> 3x3 -> 3x3 dilated + shortcut) as one launch (0: three launches; A/B switch)
 _FUSE_SHORTCUT = os.environ.get("SLU_FUSE_SHORTCUT", "1") != "0"      # A/B: ResBlock shortcut conv inside the fused tail
 _FUSE_CTX = os.environ.get("SLU_FUSE_CTX", "1") != "0"
+_PACK_MULTI = os.environ.get("SLU_PACK_MULTI", "1") != "0"          # A/B: training step packs all conv weights in one launch
 # half-precision MC inference: head conv + softmax / entropy / MI reduction over the T passes as one launch (0: logits + slu_mc_reduce)
 _FUSE_HEAD_MC = os.environ.get("SLU_FUSE_HEAD_MC", "1") != "0"
 
@@ -496,6 +497,29 @@ class SalsaNext(_FusedBlock):
         self.__dict__["_drop_event"] = side.record_event()
         return out
 
+    def _pack_training_weights(self):
+        """Training step (exact-fp32 products): the forward and data-gradient MFMA images of ALL conv weights in one launch
+        (ops.WeightPackPlan) instead of one pack launch per layer in the forward and two per layer in the backward; the per-layer caches
+        (`_Prepared.wpack`, `.dgrad`) are pointed at the plan's buffers, so the layers find them current."""
+        if not _PACK_MULTI or _TRAIN_CONV_PRECISION != "fp32":
+            return
+        owners = [(m, c) for m in self.modules() if isinstance(m, _FusedBlock) for c in m.children() if isinstance(c, nn.Conv2d)]
+        weights = [c.weight for _, c in owners]
+        if not weights or not all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w in weights):
+            return
+        keys = [_tkey(w) for w in weights]
+        plan = self.__dict__.get("_pack_plan")
+        if plan is None or not plan.matches(weights):
+            plan = self.__dict__["_pack_plan"] = ops.WeightPackPlan([w.detach() for w in weights])
+            self.__dict__["_pack_keys"] = None
+        if self.__dict__.get("_pack_keys") != keys:
+            plan.run()
+            self.__dict__["_pack_keys"] = keys
+        for i, ((m, c), w, k) in enumerate(zip(owners, weights, keys)):
+            p = m._prepared(c)
+            p.wpack, p.key = plan.fwd[i], k
+            p.dgrad["pack"], p.dgrad["key"] = plan.dgrad[i], (w.data_ptr(), w._version)
+
     def _join_dropout(self):
         ev = self.__dict__.pop("_drop_event", None)
         if ev is not None:
@@ -510,6 +534,8 @@ class SalsaNext(_FusedBlock):
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise RuntimeError("SalsaNext needs H and W divisible by 16")
         x = x.contiguous().float()
+        if not self._inference_only():
+            self._pack_training_weights()
         if scales is None and self._inference_only() and not torch.cuda.is_current_stream_capturing():
             scales = self._predraw_dropout(x.shape[0], x.device)
         if _CONV_PRECISION == "f16" and self._inference_only():

@@ -139,6 +139,27 @@ def test_wgrad_kxk_from_nchw(cuda, fam, chans, cout, n, h, w):
         assert dw2 is not None and _rel(dw2.cpu(), w2.grad) <= 1e-4
 
 
+def test_all_weights_packed_in_one_launch(cuda):
+    """ops.WeightPackPlan: forward and data-gradient MFMA images of a list of weights from ONE launch == pack_conv_weight(w) and
+    pack_conv_weight(dgrad_weight(w)) bit for bit, for every kernel family and ragged channel counts; re-running after an in-place update
+    refreshes the same buffers."""
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(co, ci, k, k, generator=g).to(cuda) for co, ci, k in [(32, 5, 1), (32, 32, 3), (64, 32, 3), (40, 48, 2), (128, 384, 1), (20, 32, 1), (256, 256, 3)]]
+    plan = ops.WeightPackPlan(ws)
+    plan.run()
+    for i, w in enumerate(ws):
+        assert torch.equal(plan.fwd[i], ops.pack_conv_weight(w)), i
+        assert torch.equal(plan.dgrad[i], ops.pack_conv_weight(ops.dgrad_weight(w))), i
+    ptrs = [t.data_ptr() for t in plan.fwd + plan.dgrad]
+    for w in ws:
+        w.mul_(0.5).add_(1.0)
+    assert plan.matches(ws) and not plan.matches(ws[:-1])
+    plan.run()
+    assert ptrs == [t.data_ptr() for t in plan.fwd + plan.dgrad]
+    for i, w in enumerate(ws):
+        assert torch.equal(plan.fwd[i], ops.pack_conv_weight(w)) and torch.equal(plan.dgrad[i], ops.pack_conv_weight(ops.dgrad_weight(w))), i
+
+
 def _layer_oracle(srcs, w, b, gamma, beta, resid, pad, dil, train, rm, rv):
     y = osalsa.fused_conv(srcs, w, b, pad, dil, 0.01)
     if train:
