@@ -579,6 +579,9 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
   }
 
   const int nq = (a.nks + KSPC - 1) / KSPC;
+#ifdef SLU_H8_PROF      // phases: input loads issued + first barrier | weight staging | second barrier | MFMAs (incl. waiting for the inputs) | epilogue
+  unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
   for (int q = 0; q < nq; ++q) {
     uint4 x[KSPC][NBW];
 #pragma unroll
@@ -594,6 +597,7 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
       }
     }
     __syncthreads();
+    H8_PROF_MARK(0)
     uint4 sw[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
@@ -611,7 +615,12 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
       const int e = tid + i * 256;
       if (NWV % 256 == 0 || e < NWV) s_a[e] = sw[i];
     }
+#ifdef SLU_H8_PROF
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    H8_PROF_MARK(1)
     __syncthreads();
+    H8_PROF_MARK(2)
 #pragma unroll
     for (int ks = 0; ks < KSPC; ++ks)
 #pragma unroll
@@ -621,6 +630,10 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
         for (int b = 0; b < NBW; ++b)
           acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(half8, x[ks][b]), acc[i][b], 0, 0, 0);
       }
+#ifdef SLU_H8_PROF
+    asm volatile("s_nop 0" ::"v"(acc[MB - 1][NBW - 1][0]));      // the last MFMA has retired
+#endif
+    H8_PROF_MARK(3)
   }
 
   const float slope_pre = (a.has_act & 3) == 1 ? a.slope : 1.0f;
@@ -629,6 +642,14 @@ __global__ __launch_bounds__(256, (MB * NBW >= 8) ? 2 : ((MB * NBW >= 4) ? 3 : 4
 #pragma unroll
     for (int b = 0; b < NBW; ++b)
       store_tile<MB * 32>(a, acc[i][b], s_epi, i * 32, i * 32, hh, live[b], (size_t)nimg[b], (size_t)hw[b], (size_t)HW, resid, out, slope_pre);
+#ifdef SLU_H8_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  H8_PROF_MARK(4)
+  if (tid == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_h8_prof[i], prof_acc[i]);
+    atomicAdd(&g_h8_prof[5], 1ull);
+  }
+#endif
 }
 
 // -----------------------------------------------------------------------------------------------------------
