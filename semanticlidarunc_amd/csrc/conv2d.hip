@@ -26,6 +26,7 @@ namespace {
 template <int KS, int DIL, int PAD, int CK, int MB, int WM, int WN, int RPW, bool GEN>
 __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2) ? 3 : 4)) void conv_fwd_kernel(const ConvArgs a, const float* __restrict__ resid, float* __restrict__ out) {
   constexpr int NT = 64 * WM * WN;
+  constexpr bool _PIN = true;
   constexpr int TW = 64, TH = WN * RPW, NB = 2 * RPW;
   constexpr int XO = PAD ? 4 : 0;                 // the LDS tile starts XO (16-byte aligned) columns left of x0
   constexpr int LW = TW + 2 * XO, LH = TH + 2 * PAD, LW4 = LW / 4;
@@ -142,21 +143,27 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
       if (NWV % NT == 0 || e < NWV) reinterpret_cast<float4*>(s_w)[e] = sw[i];
     }
     __syncthreads();
-    // ---- K-steps ----
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
+    // ---- K-steps: the MB + NB operand reads of step s + 1 are issued before the MB * NB MFMAs of step s, in THIS order (sched_barrier pins
+    //      it; left alone the compiler emits read, wait, MFMA, read, wait, ... and every 64-cycle MFMA starts with an LDS round trip) ----
+    float av[2][MB], bv[2][NB];
+    auto read_step = [&](int s, int set) {
       const int tap = s / HALF, pp = s % HALF;
       const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
-      float av[MB];
 #pragma unroll
-      for (int i = 0; i < MB; ++i) av[i] = s_w[abase + (i * KSTEPS + s) * 64];
+      for (int i = 0; i < MB; ++i) av[set][i] = s_w[abase + (i * KSTEPS + s) * 64];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int rr = b >> 1, cb = b & 1;
-        const float bv = s_in[bbase + (2 * pp) * PLANE + (rr + dy) * LW + cb * 32 + dx];
+      for (int b = 0; b < NB; ++b) bv[set][b] = s_in[bbase + (2 * pp) * PLANE + ((b >> 1) + dy) * LW + (b & 1) * 32 + dx];
+    };
+    read_step(0, 0);
 #pragma unroll
-        for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][b], 0, 0, 0);
-      }
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + 1 < KSTEPS) read_step(s + 1, (s + 1) & 1);
+      if (_PIN) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][b], acc[i][b], 0, 0, 0);
+      if (_PIN) __builtin_amdgcn_sched_barrier(0);
     }
   }
 
