@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Guard for the counted-wait kernels (tail2_h8_kernel, ring3_h8_kernel: DESIGN 3.1g).  Their speed -- not their results -- depends on two
+things the compiler is free to change: that it leaves the `s_waitcnt vmcnt(N)` of the source alone, and that it does not add its own
+`vmcnt(0)` inside the tile loop (it does for LDS reads without a TBAA tag and for tracked global loads once LDS-DMAs are interleaved).  This
+script disassembles the gfx950 code objects of libslu_hip.so and reports, per instantiation, the vmcnt values in the tile loop; it exits
+non-zero when a loop contains more `vmcnt(0)` than the first-tile branches account for.
+
+    python tools/check_counted_waits.py [path/to/libslu_hip.so]
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+so = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                         "semanticlidarunc_amd", "libslu_hip.so"))
+KERNELS = re.compile(r"^(\S*(tail2_h8_kernel|ring3_h8_kernel)\S*)>?:$")
+bad = 0
+with tempfile.TemporaryDirectory() as tmp:
+    local = os.path.join(tmp, "lib.so")
+    shutil.copy(so, local)                                  # llvm-objdump --offloading writes the bundles next to its input
+    subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", local], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for f in sorted(os.listdir(tmp)):
+        if "amdgcn" not in f:
+            continue
+        asm = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+        name, waits, nbar = None, [], 0
+        def flush():
+            global bad
+            if name is None:
+                return
+            inner = [w for w in waits]
+            zeros = sum(1 for w in inner if w == 0)
+            counted = [w for w in inner if w > 0]
+            # expected vmcnt(0): set-up (<= 6), one per first-tile position (<= positions), the kernel's exit, RESWAIT == 0 forms (<= 1)
+            limit = 6 + max(1, nbar) + 2
+            flag = "" if zeros <= limit and counted else "   <-- more vmcnt(0) than the first-tile branches explain" if counted else "   <-- no counted wait left"
+            if flag:
+                bad += 1
+            print(f"{name[:90]:90s} barriers {nbar:2d}  counted {sorted(set(counted))}  vmcnt(0) x{zeros}{flag}")
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                flush()
+                name = m.group(1) if ("tail2_h8_kernel" in m.group(1) or "ring3_h8_kernel" in m.group(1)) else None
+                waits, nbar = [], 0
+                continue
+            if name is None:
+                continue
+            w = re.search(r"s_waitcnt\s+vmcnt\((\d+)\)", line)
+            if w:
+                waits.append(int(w.group(1)))
+            if "s_barrier" in line:
+                nbar += 1
+        flush()
+sys.exit(1 if bad else 0)
