@@ -1,8 +1,9 @@
 """Oracle: the ResNet-FPN model as a pure function of a ``state_dict`` (plain torch CPU ops).  TEST INFRASTRUCTURE ONLY.
 
-Restates ``src/models/semanticFCN.py:8-40,266-354`` (resnet18/34 branch :145-153,:305-314) together with the public
-torchvision 0.19 ``BasicBlock`` / ``resnet18`` / ``resnet34`` architecture (conv3x3(stride)-BN-ReLU-conv3x3-BN,
-1x1-stride conv + BN downsample, add, ReLU; layers [2,2,2,2] / [3,4,6,3]; widths 64-128-256-512), which is a third-party
+Restates ``src/models/semanticFCN.py:8-40,266-354`` (resnet18/34/50 branch :145-153,:305-314) together with the public
+torchvision 0.19 ``BasicBlock`` / ``Bottleneck`` / ``resnet18`` / ``resnet34`` / ``resnet50`` architecture (BasicBlock:
+conv3x3(stride)-BN-ReLU-conv3x3-BN; Bottleneck (v1.5): conv1x1-BN-ReLU-conv3x3(stride)-BN-ReLU-conv1x1(x4)-BN;
+1x1-stride conv + BN downsample, add, ReLU; layers [2,2,2,2] / [3,4,6,3]; widths 64-128-256-512 (x4 for resnet50)), which is a third-party
 dependency absent from the reference tree (pinned torchvision 0.19.1, docker/Dockerfile:195).
 
 Pinning: torchvision cannot be imported here, so the backbone half is restated from its published definition (parity of
@@ -16,7 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-LAYERS = {"resnet18": [2, 2, 2, 2], "resnet34": [3, 4, 6, 3]}
+LAYERS = {"resnet18": [2, 2, 2, 2], "resnet34": [3, 4, 6, 3], "resnet50": [3, 4, 6, 3]}
+EXPANSION = {"resnet18": 1, "resnet34": 1, "resnet50": 4}
 
 
 # ---- a CPU-runnable torchvision-shaped ResNet (served to the reference through a stub `torchvision.models`) ----
@@ -39,9 +41,32 @@ class BasicBlockRef(nn.Module):
         return self.relu(out + idn)
 
 
-class ResNetRef(nn.Module):
-    def __init__(self, layers, **_ignored):
+class BottleneckRef(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)      # v1.5: the stride sits on the 3x3
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample, self.stride = downsample, stride
+
+    def forward(self, x):
+        idn = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idn)
+
+
+class ResNetRef(nn.Module):
+    def __init__(self, layers, block=None, **_ignored):
+        super().__init__()
+        self.block = block or BasicBlockRef
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -52,24 +77,25 @@ class ResNetRef(nn.Module):
         self.layer3 = self._make(256, layers[2], 2)
         self.layer4 = self._make(512, layers[3], 2)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
-        self.fc = nn.Linear(512, 1000)
+        self.fc = nn.Linear(512 * self.block.expansion, 1000)
 
     def _make(self, planes, blocks, stride):
-        down = None
-        if stride != 1 or self.inplanes != planes:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
-        seq = [BasicBlockRef(self.inplanes, planes, stride, down)]
-        self.inplanes = planes
-        seq += [BasicBlockRef(planes, planes) for _ in range(1, blocks)]
+        down, e = None, self.block.expansion
+        if stride != 1 or self.inplanes != planes * e:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * e, 1, stride, bias=False), nn.BatchNorm2d(planes * e))
+        seq = [self.block(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * e
+        seq += [self.block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*seq)
 
 
 def torchvision_models_stub():
-    """A module object that can stand in for `torchvision.models` (resnet18 / resnet34 only; `pretrained` ignored)."""
+    """A module object that can stand in for `torchvision.models` (resnet18 / resnet34 / resnet50 only; `pretrained` ignored)."""
     import types
     m = types.ModuleType("torchvision.models")
     m.resnet18 = lambda *a, **k: ResNetRef(LAYERS["resnet18"])
     m.resnet34 = lambda *a, **k: ResNetRef(LAYERS["resnet34"])
+    m.resnet50 = lambda *a, **k: ResNetRef(LAYERS["resnet50"], BottleneckRef)
     return m
 
 
@@ -87,9 +113,20 @@ def _block(x, sd, p, stride):
     return F.relu(out + idn)
 
 
+def _bottleneck(x, sd, p, stride):
+    idn = x
+    if (p + ".downsample.0.weight") in sd:
+        idn = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride=stride), sd, p + ".downsample.1")
+    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], None), sd, p + ".bn1"))
+    out = F.relu(_bn(F.conv2d(out, sd[p + ".conv2.weight"], None, stride=stride, padding=1), sd, p + ".bn2"))
+    out = _bn(F.conv2d(out, sd[p + ".conv3.weight"], None), sd, p + ".bn3")
+    return F.relu(out + idn)
+
+
 def _stage(x, sd, name, nblocks, stride):
     for b in range(nblocks):
-        x = _block(x, sd, f"backbone.{name}.{b}", stride if b == 0 else 1)
+        p = f"backbone.{name}.{b}"
+        x = (_bottleneck if (p + ".conv3.weight") in sd else _block)(x, sd, p, stride if b == 0 else 1)
     return x
 
 

@@ -47,9 +47,26 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
 
-class ResNetContainer(nn.Module):
-    def __init__(self, layers: List[int]):
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)      # torchvision's v1.5: the stride sits on the 3x3
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNetContainer(nn.Module):
+    def __init__(self, layers: List[int], block=None):
+        super().__init__()
+        self.block = block or BasicBlock
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -60,22 +77,22 @@ class ResNetContainer(nn.Module):
         self.layer3 = self._make_layer(256, layers[2], 2)
         self.layer4 = self._make_layer(512, layers[3], 2)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
-        self.fc = nn.Linear(512, 1000)
+        self.fc = nn.Linear(512 * self.block.expansion, 1000)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def _make_layer(self, planes, blocks, stride):
-        down = None
-        if stride != 1 or self.inplanes != planes:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
-        seq = [BasicBlock(self.inplanes, planes, stride, down)]
-        self.inplanes = planes
-        seq += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        down, e = None, self.block.expansion
+        if stride != 1 or self.inplanes != planes * e:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * e, 1, stride, bias=False), nn.BatchNorm2d(planes * e))
+        seq = [self.block(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * e
+        seq += [self.block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*seq)
 
 
-_RESNETS = {"resnet18": [2, 2, 2, 2], "resnet34": [3, 4, 6, 3]}
+_RESNETS = {"resnet18": ([2, 2, 2, 2], BasicBlock), "resnet34": ([3, 4, 6, 3], BasicBlock), "resnet50": ([3, 4, 6, 3], Bottleneck)}
 
 
 class AttentionModule(nn.Module):
@@ -105,10 +122,10 @@ class SemanticNetworkWithFPN(nn.Module):
         if resnet_type is not None:          # stale keyword of src/inference_ouster.py:35
             backbone = resnet_type
         if backbone not in _RESNETS:
-            if backbone in ("resnet50", "regnet_y_400mf", "regnet_y_800mf", "regnet_y_1_6gf", "regnet_y_3_2gf", "shufflenet_v2_x0_5",
+            if backbone in ("regnet_y_400mf", "regnet_y_800mf", "regnet_y_1_6gf", "regnet_y_3_2gf", "shufflenet_v2_x0_5",
                             "shufflenet_v2_x1_0", "shufflenet_v2_x1_5", "shufflenet_v2_x2_0", "squeezenet1_0", "efficientnet_v2_s",
                             "efficientnet_v2_m", "efficientnet_v2_l"):
-                raise NotImplementedError(f"backbone '{backbone}' is not implemented on the HIP path yet (resnet18 / resnet34 are)")
+                raise NotImplementedError(f"backbone '{backbone}' is not implemented on the HIP path yet (resnet18 / resnet34 / resnet50 are)")
             raise ValueError("Invalid ResNet type. Supported types: 'resnet18', 'resnet34', 'resnet50', 'regnet_y_400mf','regnet_y_800mf', "
                              "'regnet_y_1_6gf', 'regnet_y_3_2gf', 'shufflenet_v2_x0_5', 'shufflenet_v2_x1_0', 'shufflenet_v2_x1_5', "
                              "'shufflenet_v2_x2_0.")
@@ -134,12 +151,14 @@ class SemanticNetworkWithFPN(nn.Module):
         """The torchvision-shaped ResNet with the reference's surgery (semanticFCN.py:146-153): conv1 replaced by a 3x3 / stride-1 conv
         over input + meta channels, `stem` = conv1 -> relu -> maxpool (bn1 skipped), layerN aliases.  Returns the channel ladder."""
         self.meta_channel_dim = meta_channel_dim
-        self.backbone = ResNetContainer(_RESNETS[backbone])
+        layers, block = _RESNETS[backbone]
+        self.backbone = ResNetContainer(layers, block)
         self.backbone.conv1 = nn.Conv2d(input_channels + meta_channel_dim, 64, 3, 1, 1, bias=False)
         self.stem = nn.Sequential(self.backbone.conv1, self.backbone.relu, self.backbone.maxpool)
         self.layer1, self.layer2 = self.backbone.layer1, self.backbone.layer2
         self.layer3, self.layer4 = self.backbone.layer3, self.backbone.layer4
-        return [512, 256, 128, 64, 32]
+        top = 512 * block.expansion                      # semanticFCN.py:85-96: 512 (resnet18 / 34), 2048 (resnet50)
+        return [top, top // 2, top // 4, top // 8, top // 16]
 
     def _check_inputs(self, x, meta_channel):
         if not (isinstance(x, torch.Tensor) and isinstance(meta_channel, torch.Tensor)) or x.dim() != 4 or meta_channel.dim() != 4:
@@ -198,8 +217,15 @@ class SemanticNetworkWithFPN(nn.Module):
             b = b + conv_b.detach() * a
         return conv_w.detach() * a.view(-1, 1, 1, 1), b
 
-    def _conv(self, name, conv: nn.Conv2d, bn, srcs, act="relu", resid=None, late=False):
-        p = self._prep(name, lambda: (*self._fold(conv.weight, conv.bias, bn), conv.kernel_size[0], conv.dilation[0], conv.padding[0]),
+    def _conv(self, name, conv: nn.Conv2d, bn, srcs, act="relu", resid=None, late=False, tail_first: int = 0):
+        """tail_first = m > 0: the sources are given as (last m input channels, the rest) -- the packed weight's input channels are rotated
+        to match (a channel prefix `cuse` is only honoured on the LAST source of a fused conv)."""
+        def make():
+            w, b = self._fold(conv.weight, conv.bias, bn)
+            if tail_first:
+                w = torch.cat([w[:, -tail_first:], w[:, :-tail_first]], 1)
+            return w, b, conv.kernel_size[0], conv.dilation[0], conv.padding[0]
+        p = self._prep(name, make,
                        conv.weight, conv.bias, *(() if bn is None else (bn.weight, bn.bias, bn.running_mean, bn.running_var)))
         return ops.conv2d_fused(srcs, p.wpack, p.cout, p.k, p.dil, p.pad, bias=p.bias, resid=resid, precision=p.precision,
                                 act=act, act_after_resid=late)
@@ -253,6 +279,9 @@ class SemanticNetworkWithFPN(nn.Module):
         """One ResNet stage.  meta_k: the down-sampled meta channels that overwrite the last m channels of x (or None)."""
         for bi, blk in enumerate(layer):
             n = f"{lname}.{bi}"
+            if isinstance(blk, Bottleneck):
+                x = self._bottleneck(n, blk, x, meta_k if bi == 0 else None)
+                continue
             if bi == 0 and blk.stride == 2:
                 cx = x.shape[1]
                 if meta_k is not None:
@@ -270,6 +299,22 @@ class SemanticNetworkWithFPN(nn.Module):
                 idn = x
             x = self._conv(n + ".conv2", blk.conv2, blk.bn2, [ConvSource(o1)], act="relu", resid=idn, late=True)
         return x
+
+    def _bottleneck(self, n: str, blk: Bottleneck, x, meta_k):
+        """conv1x1-BN-ReLU, conv3x3(stride)-BN-ReLU, conv1x1-BN, + identity (1x1-stride conv + BN where the shape changes), ReLU.  meta_k: the
+        meta channels that overwrite the last m channels of x on the way in (first block of a stride-2 stage)."""
+        cx = x.shape[1]
+        m = 0 if meta_k is None else meta_k.shape[1]
+        src = [ConvSource(x)] if meta_k is None else [ConvSource(meta_k), ConvSource(x, None, False, 0, cx - m)]      # (meta, x[:, :-m])
+        o1 = self._conv(n + ".conv1", blk.conv1, blk.bn1, src, tail_first=m)
+        if blk.stride == 2:
+            o2 = self._conv_s2(n + ".conv2", blk.conv2, blk.bn2, ops.space_to_depth2(o1), o1.shape[1])
+            s2d = ops.space_to_depth2(x) if meta_k is None else ops.space_to_depth2_cat(x, cx - meta_k.shape[1], meta_k)
+            idn = self._conv(n + ".down", blk.downsample[0], blk.downsample[1], [ConvSource(s2d, None, False, 0, cx)], act="none")   # phase (0,0)
+        else:
+            o2 = self._conv(n + ".conv2", blk.conv2, blk.bn2, [ConvSource(o1)])
+            idn = x if blk.downsample is None else self._conv(n + ".down", blk.downsample[0], blk.downsample[1], src, act="none", tail_first=m)
+        return self._conv(n + ".conv3", blk.conv3, blk.bn3, [ConvSource(o2)], act="relu", resid=idn, late=True)
 
     def _attend(self, name, att: AttentionModule, x):
         def make_qk():

@@ -54,7 +54,7 @@ class SemanticNetworkWithFPN(_FPNBase):
     def __init__(self, backbone="resnet18", input_channels=2, meta_channel_dim=3, interpolation_mode="nearest", num_classes=3,
                  attention=True, multi_scale_meta=True):
         nn.Module.__init__(self)
-        if backbone not in _RESNETS:
+        if backbone not in _RESNETS or backbone == "resnet50":      # resnet50 is on the HIP path for semanticFCN only so far
             known = ("resnet50", "regnet_y_400mf", "regnet_y_800mf", "regnet_y_1_6gf", "regnet_y_3_2gf", "shufflenet_v2_x0_5", "shufflenet_v2_x1_0",
                      "shufflenet_v2_x1_5", "shufflenet_v2_x2_0", "squeezenet1_0", "efficientnet_v2_s", "efficientnet_v2_m", "efficientnet_v2_l")
             if backbone in known:

@@ -336,6 +336,24 @@ def test_kitti_sample_and_projection_options_match_reference():
         assert np.array_equal(img, g[f"proj:{tag}:img"]) and np.allclose(th, g[f"proj:{tag}:theta"], rtol=0, atol=0)
 
 
+def test_fpn_resnet50_oracle_matches_reference_golden():
+    """a3 widened to the Bottleneck backbone (golden: tools/gen_golden_r02.py fpn_resnet50 -- the reference's own semanticFCN wiring on this
+    repo's state_dict, through the stub torchvision that serves oracle.fpn's restated ResNet)."""
+    from oracle import fpn as ofpn
+    from semanticlidarunc_amd.fpn import SemanticNetworkWithFPN
+    from semanticlidarunc_amd.testing import randomize_bn_
+    g = golden("fpn_resnet50_m3_c5")
+    torch.manual_seed(0)
+    model = randomize_bn_(SemanticNetworkWithFPN(backbone="resnet50", input_channels=2, meta_channel_dim=3, num_classes=5), 3).eval()
+    sd = model.state_dict()
+    fl = [v for v in sd.values() if v.is_floating_point()]
+    assert np.allclose([sum(float(v.double().sum()) for v in fl), sum(float(v.double().abs().sum()) for v in fl)], g["sd_digest"], rtol=1e-10)
+    assert sd["backbone.layer4.2.conv3.weight"].shape == (2048, 512, 1, 1) and sd["fpn_block4.0.weight"].shape == (1024, 2048, 3, 3)
+    with torch.no_grad():
+        y = ofpn.fpn_forward(sd, _t(g["x"]), _t(g["meta"]), "resnet50", True, True)
+    assert float((y - _t(g["out"])).abs().max()) <= 1e-5 * max(1.0, float(np.abs(g["out"]).max()))
+
+
 def test_fpn_opt_oracle_matches_reference_golden():
     """f-4 (golden: tools/gen_golden_r02.py fpn_opt, the reference's own semanticFCN_opt head wiring on this repo's state_dict)."""
     from oracle import fpn_opt as ofpo

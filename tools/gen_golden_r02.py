@@ -214,6 +214,39 @@ def gen_fpn_opt():
     print("  oracle.fpn_opt == reference baselines.Reichert.semanticFCN_opt (head wiring; backbone internals restated)")
 
 
+def gen_fpn_resnet50():
+    """a3 widened: models/semanticFCN.py with the resnet50 backbone (Bottleneck blocks, channel ladder 2048..128) through the stub
+    torchvision.models that serves oracle.fpn's restated ResNet: the reference's own wiring on the state_dict of this repo's class."""
+    from oracle import fpn as ofpn
+    from semanticlidarunc_amd.fpn import SemanticNetworkWithFPN as MyFPN
+    from semanticlidarunc_amd.testing import randomize_bn_
+    tv = types.ModuleType("torchvision")
+    tv.models = ofpn.torchvision_models_stub()
+    sys.modules["torchvision"], sys.modules["torchvision.models"] = tv, tv.models
+    from models.semanticFCN import SemanticNetworkWithFPN as RefFPN        # the reference's own wiring
+    tag, kw, shape = "resnet50_m3_c5", dict(backbone="resnet50", input_channels=2, meta_channel_dim=3, num_classes=5), (1, 32, 64)
+    torch.manual_seed(0)
+    mine = randomize_bn_(MyFPN(**kw), 3).eval()
+    ref_f = RefFPN(**kw)
+    sdf = mine.state_dict()
+    assert list(sdf.keys()) == list(ref_f.state_dict().keys()), "state_dict key order differs from the reference class"
+    assert all(tuple(a.shape) == tuple(b.shape) for a, b in zip(sdf.values(), ref_f.state_dict().values()))
+    ref_f.load_state_dict(sdf)
+    ref_f.eval()
+    g = torch.Generator().manual_seed(52)
+    xf = torch.randn(shape[0], 2, shape[1], shape[2], generator=g) * torch.tensor([20.0, 0.3]).view(1, 2, 1, 1)
+    mf = torch.randn(shape[0], kw["meta_channel_dim"], shape[1], shape[2], generator=g) * 5.0
+    with torch.no_grad():
+        yr = ref_f(xf, mf)
+        yo = ofpn.fpn_forward(sdf, xf, mf, kw["backbone"], True, True)
+    d = float((yr - yo).abs().max())
+    print(f"FPN {tag}: |oracle - reference| = {d:.3e}  (out min {float(yr.min()):.3f}, max {float(yr.max()):.3f})")
+    assert d <= 1e-5 * max(1.0, float(yr.abs().max()))
+    fl = {k: v for k, v in sdf.items() if v.is_floating_point()}
+    digest = np.array([sum(float(v.double().sum()) for v in fl.values()), sum(float(v.double().abs().sum()) for v in fl.values())])
+    save("fpn_" + tag, x=xf.numpy(), meta=mf.numpy(), out=yr.numpy(), sd_digest=digest)
+
+
 def gen_kl_weighted():
     """KL_offClasses_to_uniform(with_conf_weighting=True) (losses/regularizers.py:375-385): value and gradient, two gammas."""
     from losses import regularizers as ref_reg                           # reference
@@ -236,7 +269,7 @@ def gen_kl_weighted():
     save("kl_off_weighted_2x20x8x64", **out)
 
 
-GENERATORS = {"ece": gen_ece, "kitti": gen_kitti, "fpn_opt": gen_fpn_opt, "kl_weighted": gen_kl_weighted}
+GENERATORS = {"ece": gen_ece, "kitti": gen_kitti, "fpn_opt": gen_fpn_opt, "fpn_resnet50": gen_fpn_resnet50, "kl_weighted": gen_kl_weighted}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(GENERATORS)):
