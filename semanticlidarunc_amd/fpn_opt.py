@@ -1,5 +1,5 @@
 """The `semanticFCN_opt` variant of the ResNet-FPN segmenter on MI355X -- what the reference's `train_semantics.py:134` builds for
-`baseline: Reichert` (src/baselines/Reichert/semanticFCN_opt.py:109-455) -- for the resnet18 / resnet34 backbones.
+`baseline: Reichert` (src/baselines/Reichert/semanticFCN_opt.py:109-455) -- for the resnet18 / resnet34 / resnet50 backbones.
 
 Same encoder as `fpn.SemanticNetworkWithFPN` (shared code); the head differs:
   SpatialAttention (:73-85)   1x1 (C -> C/8, no bias) + ReLU -> 1x1 (-> 1) -> softmax over H*W -> x * w + x
@@ -54,11 +54,11 @@ class SemanticNetworkWithFPN(_FPNBase):
     def __init__(self, backbone="resnet18", input_channels=2, meta_channel_dim=3, interpolation_mode="nearest", num_classes=3,
                  attention=True, multi_scale_meta=True):
         nn.Module.__init__(self)
-        if backbone not in _RESNETS or backbone == "resnet50":      # resnet50 is on the HIP path for semanticFCN only so far
-            known = ("resnet50", "regnet_y_400mf", "regnet_y_800mf", "regnet_y_1_6gf", "regnet_y_3_2gf", "shufflenet_v2_x0_5", "shufflenet_v2_x1_0",
+        if backbone not in _RESNETS:
+            known = ("regnet_y_400mf", "regnet_y_800mf", "regnet_y_1_6gf", "regnet_y_3_2gf", "shufflenet_v2_x0_5", "shufflenet_v2_x1_0",
                      "shufflenet_v2_x1_5", "shufflenet_v2_x2_0", "squeezenet1_0", "efficientnet_v2_s", "efficientnet_v2_m", "efficientnet_v2_l")
             if backbone in known:
-                raise NotImplementedError(f"backbone '{backbone}' is not implemented on the HIP path yet (resnet18 / resnet34 are)")
+                raise NotImplementedError(f"backbone '{backbone}' is not implemented on the HIP path yet (resnet18 / resnet34 / resnet50 are)")
             raise ValueError("Invalid ResNet type. Supported types: 'resnet18', 'resnet34', 'resnet50', 'regnet_y_400mf','regnet_y_800mf', "
                              "'regnet_y_1_6gf', 'regnet_y_3_2gf', 'shufflenet_v2_x0_5', 'shufflenet_v2_x1_0', 'shufflenet_v2_x1_5', "
                              "'shufflenet_v2_x2_0.")

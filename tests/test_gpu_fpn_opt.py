@@ -16,7 +16,8 @@ from semanticlidarunc_amd.utils.mc_dropout import mc_forward, set_dropout_mode
 pytestmark = pytest.mark.gpu
 CASES = {"resnet18_m6_c20": dict(backbone="resnet18", input_channels=2, meta_channel_dim=6, num_classes=20),
          "resnet34_m3_c21_noatt": dict(backbone="resnet34", input_channels=2, meta_channel_dim=3, num_classes=21, attention=False,
-                                       multi_scale_meta=False)}
+                                       multi_scale_meta=False),
+         "resnet50_m3_c5": dict(backbone="resnet50", input_channels=2, meta_channel_dim=3, num_classes=5)}      # Bottleneck backbone
 
 
 def _t(a):

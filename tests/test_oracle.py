@@ -361,7 +361,8 @@ def test_fpn_opt_oracle_matches_reference_golden():
     from semanticlidarunc_amd.testing import randomize_bn_
     for tag, kw in (("resnet18_m6_c20", dict(backbone="resnet18", input_channels=2, meta_channel_dim=6, num_classes=20)),
                     ("resnet34_m3_c21_noatt", dict(backbone="resnet34", input_channels=2, meta_channel_dim=3, num_classes=21, attention=False,
-                                                   multi_scale_meta=False))):
+                                                   multi_scale_meta=False)),
+                    ("resnet50_m3_c5", dict(backbone="resnet50", input_channels=2, meta_channel_dim=3, num_classes=5))):
         g = golden("fpn_opt_" + tag)
         torch.manual_seed(0)
         m = randomize_bn_(SemanticNetworkWithFPN(**kw), 3).eval()

@@ -170,7 +170,8 @@ def gen_fpn_opt():
     from baselines.Reichert.semanticFCN_opt import SemanticNetworkWithFPN as RefOpt        # the reference's own wiring
     for tag, kw, shape in (("resnet18_m6_c20", dict(backbone="resnet18", input_channels=2, meta_channel_dim=6, num_classes=20), (2, 32, 128)),
                            ("resnet34_m3_c21_noatt", dict(backbone="resnet34", input_channels=2, meta_channel_dim=3, num_classes=21,
-                                                          attention=False, multi_scale_meta=False), (1, 16, 64))):
+                                                          attention=False, multi_scale_meta=False), (1, 16, 64)),
+                           ("resnet50_m3_c5", dict(backbone="resnet50", input_channels=2, meta_channel_dim=3, num_classes=5), (1, 32, 64))):
         torch.manual_seed(0)
         mine = randomize_bn_(MyOpt(**kw), 3).eval()
         with torch.no_grad():                                # non-trivial GroupNorm affines
