@@ -47,5 +47,8 @@ for li, (parts, cout, k, dil, pad, H, W, res) in enumerate(LAYERS):
     nwg = max(1, v[5])
     tot = sum(v[:5])
     us = e0.elapsed_time(e1) * 1e3
+    if tot == 0:
+        print(f"L{li} {parts}->{cout} k{k}d{dil} {H}x{W}: {us:7.1f} us -- not the tiled kernel (ring3_h8_kernel takes the full-resolution 3x3 layers)", flush=True)
+        continue
     print(f"L{li} {parts}->{cout} k{k}d{dil} {H}x{W}: {us:7.1f} us, {nwg} WGs, clocks/WG {tot / nwg:9.0f} ({tot / nwg / us:6.1f} clk/us): "
           + "  ".join(f"{nm} {100.0 * x / tot:4.1f}%" for nm, x in zip(("wait", "barrier", "issue", "mfma", "epilogue"), v[:5])), flush=True)
