@@ -314,7 +314,7 @@ inline unsigned cap(size_t n, unsigned c) { return (unsigned)(n > c ? c : (n ? n
 
 extern "C" int slu_bn_stats(const float* y, int N, int C, int HW, double* sum, double* sumsq, slu_stream_t stream) {
   if (!y || !sum || !sumsq || N <= 0 || C <= 0 || HW <= 0 || C > 65535) return SLU_EINVAL;
-  const unsigned gx = cap(((size_t)N * HW + 2047) / 2048, 256);
+  const unsigned gx = cap(((size_t)N * HW + 8191) / 8192, 64);      // one fp64 atomic (pair) per workgroup and channel: keep the chains short
   if (HW % 4 == 0 && !((uintptr_t)y & 15))
     hipLaunchKernelGGL((chan_reduce_kernel<0, 4>), dim3(gx, C), dim3(256), 0, slu_stream(stream), y, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, N, C, HW, sum, sumsq);
@@ -327,7 +327,7 @@ extern "C" int slu_bn_stats(const float* y, int N, int C, int HW, double* sum, d
 extern "C" int slu_bn_bwd_reduce(const float* dz, const float* y, const float* mean, const float* invstd, int N, int C, int HW,
                                  double* s1, double* s2, slu_stream_t stream) {
   if (!dz || !y || !mean || !invstd || !s1 || !s2 || N <= 0 || C <= 0 || HW <= 0 || C > 65535) return SLU_EINVAL;
-  const unsigned gx = cap(((size_t)N * HW + 2047) / 2048, 256);
+  const unsigned gx = cap(((size_t)N * HW + 8191) / 8192, 64);      // one fp64 atomic (pair) per workgroup and channel: keep the chains short
   if (HW % 4 == 0 && !(((uintptr_t)dz | (uintptr_t)y) & 15))
     hipLaunchKernelGGL((chan_reduce_kernel<1, 4>), dim3(gx, C), dim3(256), 0, slu_stream(stream), dz, y, mean, invstd, N, C, HW, s1, s2);
   else
@@ -368,7 +368,7 @@ extern "C" int slu_act_affine_bwd(const float* dz, const float* y, const float* 
                                   int has_act, int N, int C, int HW, float* da, double* dbias, slu_stream_t stream) {
   if (!dz || !da || N <= 0 || C <= 0 || HW <= 0 || C > 65535) return SLU_EINVAL;
   if ((has_act || k3) && !y) return SLU_EINVAL;
-  const unsigned gx = cap(((size_t)N * HW + 2047) / 2048, 256);
+  const unsigned gx = cap(((size_t)N * HW + 8191) / 8192, 64);      // one fp64 atomic (pair) per workgroup and channel: keep the chains short
   if (HW % 4 == 0 && !(((uintptr_t)dz | (uintptr_t)y | (uintptr_t)da) & 15))
     hipLaunchKernelGGL(act_affine_bwd_kernel<4>, dim3(gx, C), dim3(256), 0, slu_stream(stream), dz, y, k1, k2, k3, slope, has_act, N, C, HW, da, dbias);
   else
