@@ -3,7 +3,8 @@
 things the compiler is free to change: that it leaves the `s_waitcnt vmcnt(N)` of the source alone, and that it does not add its own
 `vmcnt(0)` inside the tile loop (it does for LDS reads without a TBAA tag and for tracked global loads once LDS-DMAs are interleaved).  This
 script disassembles the gfx950 code objects of libslu_hip.so and reports, per instantiation, the vmcnt values in the tile loop; it exits
-non-zero when a loop contains more `vmcnt(0)` than the first-tile branches account for.
+non-zero when a loop contains more `vmcnt(0)` than the first-tile branches account for, or when an instruction reads the destination of
+one of the kernels' untracked (inline-asm) register loads before a vmcnt wait (that one WOULD be a wrong result).
 
     python tools/check_counted_waits.py [path/to/libslu_hip.so]
 """
@@ -27,7 +28,7 @@ with tempfile.TemporaryDirectory() as tmp:
         if "amdgcn" not in f:
             continue
         asm = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
-        name, waits, nbar = None, [], 0
+        name, waits, nbar, pending = None, [], 0, set()
         def flush():
             global bad
             if name is None:
@@ -47,13 +48,33 @@ with tempfile.TemporaryDirectory() as tmp:
                 flush()
                 name = m.group(1) if ("tail2_h8_kernel" in m.group(1) or "ring3_h8_kernel" in m.group(1)) else None
                 waits, nbar = [], 0
+                pending.clear()
                 continue
             if name is None:
                 continue
             w = re.search(r"s_waitcnt\s+vmcnt\((\d+)\)", line)
             if w:
                 waits.append(int(w.group(1)))
+                pending.clear()                            # every register load issued so far is covered by (or older than) a wait
             if "s_barrier" in line:
                 nbar += 1
+            # the untracked register loads (inline asm, SGPR base + VGPR offset): nothing may read their destination before a vmcnt wait
+            ins = line.split("//")[0]
+            m2 = re.search(r"global_load_dwordx[24]\s+v\[(\d+):(\d+)\],\s*v\d+,\s*s\[", ins)
+            if m2:
+                pending.update(range(int(m2.group(1)), int(m2.group(2)) + 1))
+                continue
+            if pending and "global_load" not in ins:
+                ops = ins.strip().split(None, 1)
+                srcs = ops[1].split(",", 1)[1] if len(ops) > 1 and "," in ops[1] else ""
+                if ops and ops[0].startswith(("global_store", "ds_write", "v_mfma", "s_")):
+                    srcs = ops[1] if len(ops) > 1 else ""       # no destination operand first (stores) / accumulate in place
+                used = set()
+                for a, b, c in re.findall(r"v\[(\d+):(\d+)\]|\bv(\d+)\b", srcs):
+                    used.update(range(int(a), int(b) + 1) if a else [int(c)])
+                if used & pending:
+                    print(f"{name[:90]}: {ins.strip()[:80]}   <-- reads a register of an untracked load before any vmcnt wait")
+                    bad += 1
+                    pending.clear()
         flush()
 sys.exit(1 if bad else 0)
