@@ -34,7 +34,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 F16_MFMA_PEAK_TFLOPS = 2500.0       # v_mfma_f32_32x32x16_f16, dense
 F16X3_MFMA_PEAK_TFLOPS = 2500.0 / 3  # three dense f16 MFMAs (2.5 PFLOP/s) per fp32-class product
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_f16_traffic_N64.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03", "pmc_f16_traffic_N64.json")
 LIB_FILE = os.path.join(ROOT, "semanticlidarunc_amd", "libslu_hip.so")
 
 
@@ -49,6 +49,8 @@ def parse_args(argv=None):
     ap.add_argument("--passes", type=int, default=T, help="MC passes T (default: the metric's 8; 16 = configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-CPU oracle timing (and the parity block that shares its pass)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the extra BASELINE configs[1] training-step measurement")
+    ap.add_argument("--no-shared-prefix", action="store_true",
+                    help="skip the extra shared-prefix leg (so that a rocprofv3 --kernel-trace --stats run of this script contains strict steps only)")
     ap.add_argument("--shared-prefix", action="store_true",
                     help="MC schedule that computes the layers no active Dropout2d can reach once per scan instead of T times "
                          "(bit-identical outputs); default: every pass fully recomputed")
@@ -373,6 +375,7 @@ def main(argv=None):
                 mb = rec[5] if len(rec) > 5 else nbytes
                 ms = e0.elapsed_time(e1)
                 f.write(f"{ms:8.3f} ms {flops/ms/1e9:7.2f} TF/s {nbytes/ms/1e6:8.1f} GB/s {mb/ms/1e6:8.1f} GB/s(min)  {tag}  {name}\n")
+    timing, timing_tags = ops.TIMING, ops.TIMING_TAGS
     ops.TIMING = None
     conv_s = sum(k[3] for k in per_kernel.values())
     conv_flops = sum(k[1] for k in per_kernel.values())
@@ -388,6 +391,26 @@ def main(argv=None):
         if pmc is None or name not in pmc or pmc[name].get("launches") != per_kernel[name][0]:
             return None
         return int((2.0 * pmc[name]["FETCH_SIZE"] + pmc[name]["WRITE_SIZE"]) * 1024)
+
+    def launch_traffic():
+        """PMC bytes of every timed conv launch, in launch order: the committed table lists the dispatches of one MC step in order
+        (`_dispatches`); the i-th timed launch of a kernel name is the i-th dispatch of that name.  None when the table does not match."""
+        if pmc is None or "_dispatches" not in pmc:
+            return None
+        by_name = {}
+        for d in pmc["_dispatches"]:
+            by_name.setdefault(d["name"], []).append(d)
+        seen, out = {}, []
+        for rec in timing:
+            k = seen.get(rec[0], 0)
+            seen[rec[0]] = k + 1
+            lst = by_name.get(rec[0], [])
+            if k >= len(lst):
+                return None
+            out.append((2.0 * lst[k]["FETCH_SIZE"] + lst[k]["WRITE_SIZE"]) * 1024)
+        if any(seen[nm] != len(by_name.get(nm, [])) for nm in seen):
+            return None
+        return out
 
     def roof(name):
         """Which roof binds a kernel (algorithmic intensity of its launches vs the ridge of its MFMA path) and how close it gets.
@@ -425,6 +448,21 @@ def main(argv=None):
                                            "gbs": round(full_res[1] / full_res[2] / 1e9, 1),
                                            "hbm_frac": round(full_res[1] / full_res[2] / 1e9 / HBM_PEAK_GBS, 4),
                                            "hbm_frac_fused_min": round(full_res[3] / full_res[2] / 1e9 / HBM_PEAK_GBS, 4)}
+    # what the step's conv launches would take if every one ran AT its binding roof: sum over launches of max(flops / MFMA peak,
+    # fused-minimum bytes / 8 TB/s); frac = that bound / the measured time of the same launches (HIP events) -- the honest whole-step figure
+    mfma_peak = {"f16": F16_MFMA_PEAK_TFLOPS, "f16x3": F16X3_MFMA_PEAK_TFLOPS, "fp32": FP32_MFMA_PEAK_TFLOPS}[args.precision] * 1e12
+    bound_s = sum(max(rec[1] / mfma_peak, (rec[5] if len(rec) > 5 else rec[2]) / (HBM_PEAK_GBS * 1e9)) for rec in timing)
+    roofline["step_roofline_bound"] = {"bound_ms": round(bound_s * 1e3, 3), "measured_conv_ms": round(conv_s * 1e3, 3),
+                                       "frac": round(bound_s / conv_s, 4), "frac_of_step": round(bound_s / (dt / args.steps), 4),
+                                       "definition": "sum over the step's conv launches of max(algorithmic flops / dense MFMA peak, fused-minimum bytes / 8 TB/s)"}
+    lt = launch_traffic()
+    if lt is not None:
+        tot = sum(lt)
+        roofline["all_convs"]["frac_traffic"] = round(tot / conv_s / 1e9 / HBM_PEAK_GBS, 4)
+        fr = sum(t for t, tag in zip(lt, timing_tags) if tag.endswith(f" {Hh}x{Ww}"))
+        if full_res[2] > 0:
+            roofline[f"encoder_{Hh}x{Ww}"]["frac_traffic"] = round(fr / full_res[2] / 1e9 / HBM_PEAK_GBS, 4)
+            roofline[f"encoder_{Hh}x{Ww}"]["traffic_gb_per_step"] = round(fr / 1e9, 3)
     roofline["kernels"] = [roof(n) for n in ranked[1:8]]
     if len(ranked) > 1:
         roofline["second"] = roofline["kernels"][0]
@@ -433,7 +471,7 @@ def main(argv=None):
     # the same workload under the opt-in MC schedule that computes the layers no active Dropout2d can reach once per scan (bit-identical
     # outputs, tests/test_gpu_model.py); reported beside the strict number, never as `value`
     shared = None
-    if not args.shared_prefix and world == 1:
+    if not args.shared_prefix and not args.no_shared_prefix and world == 1:
         for _ in range(2):
             step(True)
         torch.cuda.synchronize()

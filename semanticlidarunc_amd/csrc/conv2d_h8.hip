@@ -22,6 +22,19 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 
+// scheduling options of the 8-wave 128-channel configuration (conv_h8_kernel's OPT), as measured with tools/h8_ab.py (one process,
+// interleaved rounds, N = 64, single-source form): 15 is +1 ... +3 % on the 3x3 layers and +3 ... +7 % on the 2x2-dilated ones; two K-steps
+// per barrier paid (+6 ... +8 %) only while the per-chunk set-up was expensive and costs 2 ... 4 % since it is one scalar multiply-add
+#ifndef H8_M128_OPT_3X3
+#define H8_M128_OPT_3X3 15
+#endif
+#ifndef H8_M128_OPT_2X2
+#define H8_M128_OPT_2X2 15
+#endif
+#ifndef H8_M128_KPC2_DEFAULT
+#define H8_M128_KPC2_DEFAULT 0      // 2x2-dilated 128 / 256-channel layers: two K-steps per barrier (kept as an A/B switch, SLU_H8_KPC2=1)
+#endif
+
 namespace {
 
 struct H8Src {
@@ -123,7 +136,7 @@ __device__ uint4 g_trash_rec;
 template <int STRIDE, bool PRE>
 __device__ __forceinline__ void store_tile_full(const H8Args& a, const f32x16& acc, const float* se, int cl0, int go0, int hh, bool pix_ok, size_t n,
                                                 size_t pix, size_t HW, const uint2* __restrict__ resid, const uint2 (&rv)[4],
-                                                uint2* __restrict__ out, float slope_pre) {
+                                                uint2* __restrict__ out, float slope_pre, uintptr_t zero_addr, uintptr_t trash_addr) {
   // packed fp32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma: two channels per instruction); LeakyReLU as max(t, slope t),
   // exact for 0 <= slope <= 1 (slope_pre = 1 means "no activation"); the per-channel constants come as 16-byte LDS reads
   const float4* se4 = reinterpret_cast<const float4*>(se);
@@ -144,12 +157,54 @@ __device__ __forceinline__ void store_tile_full(const H8Args& a, const f32x16& a
     const bool ok = pix_ok && go0 + q < a.Gout;
     const size_t idx = idx0 + q * plane2;
     if (resid) {
-      const uint2 r = PRE ? rv[q] : *(ok ? resid + idx : reinterpret_cast<const uint2*>(&g_zero_rec));
+      const uint2 r = PRE ? rv[q] : *(ok ? resid + idx : reinterpret_cast<const uint2*>(zero_addr));
       t0 += __builtin_convertvector(__builtin_bit_cast(half2v, r.x), float2v);
       t1 += __builtin_convertvector(__builtin_bit_cast(half2v, r.y), float2v);
     }
-    *(ok ? out + idx : reinterpret_cast<uint2*>(&g_trash_rec)) =
+    *(ok ? out + idx : reinterpret_cast<uint2*>(trash_addr)) =
         make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v)), __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v)));
+  }
+}
+
+// The same epilogue with whole 16-byte records on the way out: the accumulator holds half of each record per lane (4 channels of
+// block q in lane half hh); v_permlane32_swap trades halves between lanes jj and jj + 32 so that lane half 0 stores the record of
+// block 2 pr and lane half 1 that of block 2 pr + 1 -- 2 store instructions per accumulator tile instead of 4.  The residual (rare on
+// the layers this serves) is added before the exchange from 8-byte loads of the lane's own channels.
+template <int STRIDE>
+__device__ __forceinline__ void store_tile_swap16(const H8Args& a, const f32x16& acc, const float* se, int cl0, int go0, int hh, bool pix_ok, size_t n,
+                                                  size_t pix, size_t HW, const uint2* __restrict__ resid, uint4* __restrict__ out, float slope_pre,
+                                                  uintptr_t zero_addr, uintptr_t trash_addr) {
+  const float4* se4 = reinterpret_cast<const float4*>(se);
+  const float2v sl = {slope_pre, slope_pre};
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    unsigned hw[4];
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      const int q = 2 * pr + q2;
+      const int c4 = (cl0 + 8 * q) / 4 + hh;
+      const float4 bi = se4[c4], ba = se4[STRIDE / 4 + c4], bb = se4[2 * STRIDE / 4 + c4];
+      float2v t0 = {acc[4 * q], acc[4 * q + 1]}, t1 = {acc[4 * q + 2], acc[4 * q + 3]};
+      t0 += float2v{bi.x, bi.y};
+      t1 += float2v{bi.z, bi.w};
+      t0 = __builtin_elementwise_max(t0, t0 * sl);
+      t1 = __builtin_elementwise_max(t1, t1 * sl);
+      t0 = t0 * float2v{ba.x, ba.y} + float2v{bb.x, bb.y};
+      t1 = t1 * float2v{ba.z, ba.w} + float2v{bb.z, bb.w};
+      if (resid) {
+        const bool okq = pix_ok && go0 + q < a.Gout;
+        const uint2 r = *(okq ? resid + (((n * a.Gout + go0 + q) * HW + pix) * 2 + hh) : reinterpret_cast<const uint2*>(zero_addr));
+        t0 += __builtin_convertvector(__builtin_bit_cast(half2v, r.x), float2v);
+        t1 += __builtin_convertvector(__builtin_bit_cast(half2v, r.y), float2v);
+      }
+      hw[2 * q2] = __builtin_bit_cast(unsigned, __builtin_convertvector(t0, half2v));
+      hw[2 * q2 + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(t1, half2v));
+    }
+    const auto s0 = __builtin_amdgcn_permlane32_swap(hw[0], hw[2], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(hw[1], hw[3], false, false);
+    const int go = go0 + 2 * pr + hh;
+    uint4* dst = (pix_ok && go < a.Gout) ? out + ((n * a.Gout + go) * HW + pix) : reinterpret_cast<uint4*>(trash_addr);
+    *dst = make_uint4(s0[0], s1[0], s0[1], s1[1]);
   }
 }
 
@@ -184,28 +239,40 @@ __device__ unsigned long long g_h8_prof[8];
 // layers).  SCALED: per-(image, channel) multipliers (Dropout2d on a concatenated input) are applied to the B
 // fragments after the LDS read.
 // -----------------------------------------------------------------------------------------------------------
-template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool SCALED, bool WRES, bool F32OUT>
+// KPC: K-steps (16 channels each) per chunk = per barrier (2 for the 2x2-dilated 128-channel layers, whose 4 taps per K-step are too
+// little MFMA work per barrier).  OPT (bit mask, the 8-wave 128-channel configuration): 1 = waves 4..7 (the SIMD partners of waves
+// 0..3) issue a tap's LDS-DMA pieces BEFORE its MFMAs, waves 0..3 after them, so the two waves of a SIMD stop stalling on the
+// address pipe at the same moment; 2 = s_setprio 1 around the MFMA cluster; 4 = the next chunk's staging set-up runs before the
+// wait + barrier instead of after; 8 = whole 16-byte records per lane on the way out (v_permlane32_swap).
+// ONE: the layer has ONE plain source (no concatenation, no batch broadcast): the staging set-up of a chunk is one 64-bit multiply-add on
+// the scalar unit instead of the source-selection chains of the general form.
+template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool SCALED, bool WRES, bool F32OUT, int KPC = 1, int OPT = 0, bool ONE = false>
 __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 || MB >= 2 || RPW >= 2) ? 2 : 3)) void conv_h8_kernel(const H8Args a, const void* __restrict__ resid,
                                                                                                        void* __restrict__ out) {
   constexpr int NWAVE = WM * WN;
-  constexpr int T = KS * KS;
+  constexpr int T = KS * KS, TS = KPC * T;          // taps per K-step, tap-steps per chunk
   constexpr int TW = 64, TH = WN * RPW, NB = 2 * RPW;
   constexpr int LW = TW + 2 * PAD, LH = TH + 2 * PAD;
   constexpr int REC = LH * LW;                      // records per channel block
   constexpr int MBLK = WM * MB;
-  constexpr int NREC_B = 2 * REC, NBLK_B = (NREC_B + 63) / 64;          // 64-record pieces of the input tile of a chunk
+  constexpr int NREC_B = KPC * 2 * REC, NBLK_B = (NREC_B + 63) / 64;    // 64-record pieces of the input tile of a chunk
   constexpr int NB_ALLOC = NBLK_B * 64;
-  constexpr int NREC_A = MBLK * T * 64, NBLK_A = MBLK * T;              // weight fragments of a chunk
+  constexpr int NREC_A = MBLK * TS * 64, NBLK_A = MBLK * TS;            // weight fragments of a chunk
   constexpr int NIB = (NBLK_B + NWAVE - 1) / NWAVE, NIA = (NBLK_A + NWAVE - 1) / NWAVE;
+  static_assert(KPC == 1 || (!WRES && !SCALED && MB == 2 && WM == 2 && WN == 4), "multi-K-step chunks: the 8-wave 128-channel configuration only");
+  static_assert(OPT == 0 || (MB == 2 && WM == 2 && WN == 4 && !F32OUT), "OPT: the 8-wave 128-channel configuration only");
+  static_assert(KPC <= 2, "pc_rc carries 2 bits of channel block");
+  static_assert(KPC == 1 || ONE, "multi-K-step chunks: single-source layers only");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_epi = reinterpret_cast<float*>(smem);                        // bias | bn_a | bn_b
   uint4* s_scale = reinterpret_cast<uint4*>(s_epi + 3 * MBLK * 32);     // [2][64] fp16 multipliers per channel block (SCALED)
   uint4* s_b = s_scale + (SCALED ? 128 : 0);                            // [2][NB_ALLOC]
-  uint4* s_a = s_b + 2 * NB_ALLOC;                                      // WRES: [MBLK][nks][T][64]; else [2][MBLK][T][64]
+  uint4* s_a = s_b + 2 * NB_ALLOC;                                      // WRES: [MBLK][nks][T][64]; else [2][MBLK][KPC][T][64]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  const bool late_half = wave >= NWAVE / 2;      // waves 4..7 share their SIMDs with waves 0..3
   const int mblk0 = blockIdx.y * MBLK;
   // contiguous run of tiles of this workgroup; workgroups that share an XCD (blockIdx.x % 8) get neighbouring runs
   int t_beg, t_end, t_step = 1;
@@ -222,6 +289,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
       t_end = (int)(nt * (w + 1) / nwg);
     }
   }
+  t_beg = __builtin_amdgcn_readfirstlane(t_beg);
+  t_end = __builtin_amdgcn_readfirstlane(t_end);
+  t_step = __builtin_amdgcn_readfirstlane(t_step);
   if (t_beg >= t_end) return;
 
   if (tid < MBLK * 32) {
@@ -236,26 +306,55 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
   const size_t HW = (size_t)a.H * a.W;
   const float slope_pre = (a.has_act & 3) == 1 ? a.slope : 1.0f;
   const int nks = a.nks;
-  const int a_stride = WRES ? nks * T * 64 : T * 64;                    // uint4 per channel block in s_a
+  const int nchunk = (nks + KPC - 1) / KPC;
+  const int a_stride = WRES ? nks * T * 64 : TS * 64;                   // uint4 per channel block in s_a
   const int abase = (wm * MB) * a_stride + lane;
   const int bbase = hh * REC + (wn * RPW) * LW + jj;                    // + (rr + dy)*LW + cb*32 + dx
 
-  struct TilePos { int x0, y0, n, i0, i1, i2; };      // i_s: the image of source s that output image n reads (once per tile, not per chunk)
-  auto decode = [&](int t) {
+  // Tile bookkeeping stays on the scalar unit: the position of the first tile comes from one division, every later one from adding the
+  // (pre-divided) tile stride with carries.  Integer division runs on the vector ALU even for uniform operands; left to itself hipcc
+  // kept the whole per-chunk staging set-up that depends on it in VGPRs (and in scratch, reloaded behind a vmcnt(0) that also drained
+  // the DMA queue) -- readfirstlane pins the results to SGPRs.
+  struct TilePos { int tx, ty, x0, y0, n, i0, i1, i2; };      // i_s: the image of source s that output image n reads (once per tile, not per chunk)
+  auto rfl = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+  const int step_tx = rfl(t_step % a.tiles_x), step_ty = rfl((t_step / a.tiles_x) % a.tiles_y), step_n = rfl(t_step / (a.tiles_x * a.tiles_y));
+  auto finish = [&](TilePos& p) __attribute__((always_inline)) {
+    p.x0 = p.tx * TW;
+    p.y0 = p.ty * TH;
+    p.i0 = p.i1 = p.i2 = p.n;
+    if constexpr (!ONE) {
+      if (a.src[0].nb) p.i0 = rfl(p.n % a.src[0].nb);
+      if (a.nsrc > 1 && a.src[1].nb) p.i1 = rfl(p.n % a.src[1].nb);
+      if (a.nsrc > 2 && a.src[2].nb) p.i2 = rfl(p.n % a.src[2].nb);
+    }
+  };
+  auto decode = [&](int t) __attribute__((always_inline)) {
     TilePos p;
-    const int tx = t % a.tiles_x;
+    p.tx = rfl(t % a.tiles_x);
     t /= a.tiles_x;
-    p.x0 = tx * TW;
-    p.y0 = (t % a.tiles_y) * TH;
-    p.n = t / a.tiles_y;
-    p.i0 = a.src[0].nb ? p.n % a.src[0].nb : p.n;
-    p.i1 = (a.nsrc > 1 && a.src[1].nb) ? p.n % a.src[1].nb : p.n;
-    p.i2 = (a.nsrc > 2 && a.src[2].nb) ? p.n % a.src[2].nb : p.n;
+    p.ty = rfl(t % a.tiles_y);
+    p.n = rfl(t / a.tiles_y);
+    finish(p);
+    return p;
+  };
+  auto advance = [&](TilePos p) __attribute__((always_inline)) {      // the tile t_step after p
+    p.tx += step_tx;
+    if (p.tx >= a.tiles_x) p.tx -= a.tiles_x, p.ty += 1;
+    p.ty += step_ty;
+    if (p.ty >= a.tiles_y) p.ty -= a.tiles_y, p.n += 1;
+    p.n += step_n;
+    finish(p);
     return p;
   };
   static_assert(SLU_MAX_SRC == 3, "TilePos carries one image index per source");
+  // The address of the zero record, once, in an SGPR pair the compiler cannot rematerialise: left alone it re-loaded the address from the
+  // GOT for every piece (s_getpc + s_load_dwordx2 + s_waitcnt lgkmcnt(0): a scalar-memory round trip in every tap's staging slot).
+  uintptr_t zero_addr = reinterpret_cast<uintptr_t>(&g_zero_rec);
+  asm volatile("" : "+s"(zero_addr));
+  uintptr_t trash_addr = reinterpret_cast<uintptr_t>(&g_trash_rec);
+  asm volatile("" : "+s"(trash_addr));
   // Per-lane description of the input-tile pieces this wave copies (the same for every chunk and tile): piece i covers
-  // records [64 (i NWAVE + wave), +64) of the [2][LH][LW] tile image; pc_rc = row | col << 8 | block << 16 | inside << 17.
+  // records [64 (i NWAVE + wave), +64) of the [2 KPC][LH][LW] tile image; pc_rc = row | col << 8 | block << 16 | inside << 20.
   int pc_rc[NIB], pc_off[NIB];
 #pragma unroll
   for (int i = 0; i < NIB; ++i) {
@@ -264,8 +363,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
     const int rem = e - g2 * REC;
     const int r = rem / LW;
     const int c = rem - r * LW;
-    pc_rc[i] = r | (c << 8) | ((g2 & 1) << 16) | ((e < NREC_B ? 1 : 0) << 17);
-    pc_off[i] = r * a.W + c;
+    pc_rc[i] = r | (c << 8) | ((g2 & (2 * KPC - 1)) << 16) | ((e < NREC_B ? 1 : 0) << 20);
+    pc_off[i] = r * a.W + c + (g2 & (2 * KPC - 1)) * (int)HW;      // block g of the chunk starts g planes after block 0 (same source)
   }
   // LDS-DMA of chunk q of tile tp into input buffer `buf` (and, unless WRES, its weight fragments into weight buffer `buf`),
   // in NPIECE pieces per wave: stage_begin fixes the wave-uniform part, stage_piece(i) issues one global_load_lds.  The
@@ -273,49 +372,61 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
   // right after the barrier, the eight waves queued on the CU's single address pipe while the matrix cores idled
   // (measured with -DSLU_H8_PROF: 25 % of the kernel in that burst, another 20 % in the barrier behind it).
   constexpr int NPIECE = NIB + (WRES ? 0 : NIA);
-  constexpr int PPT = (NPIECE + T - 1) / T;          // pieces issued after each tap
-  uintptr_t st_base0 = 0, st_base1 = 0;
-  bool st_live0 = false, st_live1 = false, st_on = false;
-  int st_x0 = 0, st_y0 = 0, st_q = 0;
+  constexpr int PPT = (NPIECE + TS - 1) / TS;        // pieces issued after each tap-step
+  // st_b0: byte address of the record at tile-image position (0, 0) of the chunk's first block; st_b1: the same for its second block
+  // MINUS one plane (pc_off carries the plane offset of the block), which equals st_b0 unless the K-step straddles two sources
+  uintptr_t st_b0 = 0, st_b1 = 0;
+  int st_g0 = 0;                                       // first channel block of the chunk (a block g is live while st_g0 + g < Gin)
+  bool st_on = false;
+  int st_x0 = 0, st_y0 = 0, st_q = 0, st_wave = wave;
   uint4 *st_db = s_b, *st_da = s_a;
-  auto stage_begin = [&](const TilePos& tp, int q, int buf) {
+  auto stage_begin = [&](const TilePos& tp, int q, int buf) __attribute__((always_inline)) {
     const int img[SLU_MAX_SRC] = {tp.i0, tp.i1, tp.i2};
-    // wave-uniform: the two channel blocks of this K-step, as byte addresses of the record at tile-image position (0, 0)
     const long long org = (long long)(tp.y0 - PAD) * a.W + (tp.x0 - PAD);
-    st_live0 = 2 * q < a.Gin;
-    st_live1 = 2 * q + 1 < a.Gin;
-    const SrcSel p0 = select_src(a, img, st_live0 ? 2 * q : 0), p1 = select_src(a, img, st_live1 ? 2 * q + 1 : 0);
-    st_base0 = reinterpret_cast<uintptr_t>(p0.ptr) + 16 * ((long long)(((size_t)p0.ns * p0.G + p0.gl) * HW) + org);
-    st_base1 = reinterpret_cast<uintptr_t>(p1.ptr) + 16 * ((long long)(((size_t)p1.ns * p1.G + p1.gl) * HW) + org);
+    st_g0 = 2 * KPC * q;
+    if constexpr (ONE) {
+      st_b0 = reinterpret_cast<uintptr_t>(a.src[0].ptr) + 16 * ((long long)(((size_t)tp.n * a.src[0].G + st_g0) * HW) + org);
+      st_b1 = st_b0;
+    } else {
+      const SrcSel p0 = select_src(a, img, st_g0 < a.Gin ? st_g0 : 0), p1 = select_src(a, img, st_g0 + 1 < a.Gin ? st_g0 + 1 : 0);
+      st_b0 = reinterpret_cast<uintptr_t>(p0.ptr) + 16 * ((long long)(((size_t)p0.ns * p0.G + p0.gl) * HW) + org);
+      st_b1 = reinterpret_cast<uintptr_t>(p1.ptr) + 16 * ((long long)(((size_t)p1.ns * p1.G + p1.gl) * HW) + org - (long long)HW);
+    }
     st_x0 = tp.x0 - PAD;
     st_y0 = tp.y0 - PAD;
     st_q = q;
     st_db = s_b + buf * NB_ALLOC;
     st_da = s_a + buf * NREC_A;
     st_on = true;
+    // an opaque copy of the wave number per chunk: otherwise every piece's LDS address and bounds test is hoisted out of the tile loop
+    // as a loop invariant, ~100 SGPRs live across it, spilled to VGPR lanes (and, in the two-K-step form, to scratch)
+    st_wave = wave;
+    asm volatile("" : "+s"(st_wave));
   };
-  auto stage_piece = [&](int i) {
+  auto stage_piece = [&](int i) __attribute__((always_inline)) {
     if (i < NIB) {
-      const int blk = i * NWAVE + wave;
+      const int blk = i * NWAVE + st_wave;
       if (NBLK_B % NWAVE == 0 || blk < NBLK_B) {
         const int rc = pc_rc[i];
         const int gy = st_y0 + (rc & 255), gx = st_x0 + ((rc >> 8) & 255);
-        const bool h1 = (rc >> 16) & 1;
-        const bool ok = (rc >> 17) && (h1 ? st_live1 : st_live0) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        const uintptr_t src = ok ? (h1 ? st_base1 : st_base0) + 16 * (long long)pc_off[i] : reinterpret_cast<uintptr_t>(&g_zero_rec);
+        const int gsel = (rc >> 16) & 3;
+        const uintptr_t gb = (!ONE && gsel == 1) ? st_b1 : st_b0;
+        const bool ok = (rc >> 20) && st_g0 + gsel < a.Gin && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const uintptr_t src = ok ? gb + 16 * (long long)pc_off[i] : zero_addr;
         SLU_GLDS16(reinterpret_cast<const uint4*>(src), st_db + blk * 64);
       }
     } else if constexpr (!WRES) {
-      const int blk = (i - NIB) * NWAVE + wave;                         // = m * T + tap
+      const int blk = (i - NIB) * NWAVE + st_wave;                      // = (m * KPC + j) * T + tap
       if (NBLK_A % NWAVE == 0 || blk < NBLK_A) {
-        const int m = blk / T;
-        const uint4* src = mblk0 + m < a.nmblk ? a.wpack + (((size_t)(mblk0 + m) * nks + st_q) * T + (blk - m * T)) * 64 + lane : &g_zero_rec;
+        const int m = blk / TS, r = blk - m * TS;                         // r = j * T + tap: K-step j of the chunk
+        const bool live = mblk0 + m < a.nmblk && (KPC == 1 || KPC * st_q + r / T < nks);
+        const uint4* src = live ? a.wpack + (((size_t)(mblk0 + m) * nks + KPC * st_q) * T + r) * 64 + lane : reinterpret_cast<const uint4*>(zero_addr);
         SLU_GLDS16(src, st_da + blk * 64);
       }
     }
   };
-  // the pieces that go after tap `tap` (compile-time indices once the tap loop is unrolled)
-  auto stage_after_tap = [&](int tap) {
+  // the pieces that go with tap-step `tap` (compile-time indices once the tap loop is unrolled)
+  auto stage_after_tap = [&](int tap) __attribute__((always_inline)) {
     if (st_on) {
 #pragma unroll
       for (int k = 0; k < PPT; ++k)
@@ -323,7 +434,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
     }
   };
   // per-channel multipliers of image n as fp16, one record per channel block (SCALED)
-  auto stage_scales = [&](int n, int par) {
+  auto stage_scales = [&](int n, int par) __attribute__((always_inline)) {
     if (tid < 64) {
       half8 h;
 #pragma unroll
@@ -355,15 +466,27 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
 #pragma unroll
   for (int i = 0; i < NPIECE; ++i) stage_piece(i);
   int buf = 0;
-  constexpr int NST = MB * NB * 4;                   // stores of a tile's epilogue, per wave (h8 output: every lane stores)
+  constexpr bool SWAP16 = (OPT & 8) != 0;            // whole 16-byte records per lane on the way out
+  constexpr int NST = MB * NB * (SWAP16 ? 2 : 4);    // stores of a tile's epilogue, per wave (h8 output: every lane stores)
   constexpr bool PRE = MB == 1 && !F32OUT;           // residual of the tile prefetched before its last MFMA phase
   const uint2* resid2 = reinterpret_cast<const uint2*>(resid);
   uint2 rv[PRE ? NB : 1][4];
+  // the staging set-up of the chunk after (tile, q): the next chunk of this tile, or the first of the next tile
+  auto setup_next = [&](int tile, int q) __attribute__((always_inline)) {
+    st_on = false;
+    if (q + 1 < nchunk) {
+      stage_begin(cur, q + 1, buf ^ 1);
+    } else if (tile + t_step < t_end) {
+      nxt = advance(cur);
+      stage_begin(nxt, 0, buf ^ 1);
+    }
+  };
 
 #ifdef SLU_H8_PROF
   unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
 #endif
-  for (int tile = t_beg; tile < t_end; tile += t_step) {
+  int tile_no = 0;
+  for (int tile = t_beg; tile < t_end; tile += t_step, ++tile_no) {
     f32x16 acc[MB][NB];                                // per tile (not carried around the loop: keeps it in the MFMA registers)
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -371,9 +494,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
-    const int spar = ((tile - t_beg) / t_step) & 1;
+    const int spar = tile_no & 1;
     if constexpr (SCALED) stage_scales(cur.n, spar);
-    for (int q = 0; q < nks; ++q) {
+    for (int q = 0; q < nchunk; ++q) {
+      // (OPT & 4) every piece of chunk (tile, q) was issued during the previous MFMA phase, so the staging state may move on to the
+      // chunk after it while this wave waits for its DMA and for the other waves
+      if constexpr ((OPT & 4) != 0) setup_next(tile, q);
       // Chunk (tile, q) has landed and nobody reads the other buffer any more.  vmcnt counts loads, LDS-DMA and stores in
       // issue order: at a tile's first chunk the only operations younger than the DMA we wait for are the NST stores of the
       // previous tile's epilogue, which may stay in flight (waiting for them would expose the HBM write latency per tile).
@@ -384,15 +510,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       H8_PROF_MARK(1)                                    // barrier
-      st_on = false;
-      if (q + 1 < nks) {
-        stage_begin(cur, q + 1, buf ^ 1);
-      } else if (tile + t_step < t_end) {
-        nxt = decode(tile + t_step);
-        stage_begin(nxt, 0, buf ^ 1);
-      }
+      if constexpr ((OPT & 4) == 0) setup_next(tile, q);
       if constexpr (PRE) {
-        if (resid && q == nks - 1) {
+        if (resid && q == nchunk - 1) {
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
             const int gy = cur.y0 + wn * RPW + (b >> 1), gx = cur.x0 + (b & 1) * 32 + jj;
@@ -402,7 +522,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
             for (int k = 0; k < 4; ++k) {
               const int go = (mblk0 + wm) * 4 + k;
               rv[b][k] = *((pix_ok && go < a.Gout) ? resid2 + (((size_t)cur.n * a.Gout + go) * HW + pix) * 2 + hh
-                                                   : reinterpret_cast<const uint2*>(&g_zero_rec));
+                                                   : reinterpret_cast<const uint2*>(zero_addr));
             }
           }
         }
@@ -414,37 +534,48 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
       if constexpr (SCALED) sc = __builtin_bit_cast(half8, s_scale[spar * 64 + 2 * q + hh]);
       {
         if constexpr (MB == 2 && WM == 2 && WN == 4) {
-          // the 8-wave 128-channel configuration (MFMA-bound layers): fragments of tap t+1 are read before the MFMAs of tap t issue, in THIS
-          // order -- sched_barrier pins it; with sched_group_barrier hints (below) the compiler still emits read, wait, MFMA, read, ...
-          // (+3 % on these layers; the other configurations spill with a second fragment set)
+          // the 8-wave 128-channel configuration (MFMA-bound layers): fragments of tap-step t+1 are read before the MFMAs of tap-step t
+          // issue, in THIS order -- sched_barrier pins it; with sched_group_barrier hints (below) the compiler still emits read, wait,
+          // MFMA, read, ... (+3 % on these layers; the other configurations spill with a second fragment set)
           half8 af[2][MB], bf[2][NB];
-          auto read_frags = [&](int set, int tap) {
+          auto read_frags = [&](int set, int ts) __attribute__((always_inline)) {
+            const int j = ts / T, tap = ts % T;          // K-step of the chunk, tap
             const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
 #pragma unroll
-            for (int i = 0; i < MB; ++i) af[set][i] = __builtin_bit_cast(half8, sa[i * a_stride + tap * 64]);
+            for (int i = 0; i < MB; ++i) af[set][i] = __builtin_bit_cast(half8, sa[i * a_stride + ts * 64]);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-              bf[set][b] = __builtin_bit_cast(half8, sb[((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
+              bf[set][b] = __builtin_bit_cast(half8, sb[j * 2 * REC + ((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
               if constexpr (SCALED) bf[set][b] *= sc;
             }
           };
           read_frags(0, 0);
 #pragma unroll
-          for (int tap = 0; tap < T; ++tap) {
-            if (tap + 1 < T) read_frags((tap + 1) & 1, tap + 1);
+          for (int ts = 0; ts < TS; ++ts) {
+            if (ts + 1 < TS) read_frags((ts + 1) & 1, ts + 1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((OPT & 1) != 0) {
+              if (late_half) stage_after_tap(ts);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr ((OPT & 2) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
-              for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap & 1][i], bf[tap & 1][b], acc[i][b], 0, 0, 0);
+              for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ts & 1][i], bf[ts & 1][b], acc[i][b], 0, 0, 0);
+            if constexpr ((OPT & 2) != 0) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            stage_after_tap(tap);
+            if constexpr ((OPT & 1) != 0) {
+              if (!late_half) stage_after_tap(ts);
+            } else {
+              stage_after_tap(ts);
+            }
           }
         } else if constexpr (MB == 1) {
           // fragments of tap t+1 are read from LDS while the MFMAs of tap t issue (two register sets, one DS read per MFMA
           // slot); with MB = 2 the second set does not fit in 256 VGPRs next to the 128 accumulator registers
           half8 af[2][MB], bf[2][NB];
-          auto read_frags = [&](int set, int tap) {
+          auto read_frags = [&](int set, int tap) __attribute__((always_inline)) {
             const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
 #pragma unroll
             for (int i = 0; i < MB; ++i) af[set][i] = __builtin_bit_cast(half8, sa[i * a_stride + tap * 64]);
@@ -509,9 +640,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
           const size_t pix = pix_ok ? (size_t)gy * a.W + gx : 0;
           if constexpr (F32OUT)
             store_tile<MBLK * 32>(a, acc[i][b], s_epi, ml * 32, (mblk0 + ml) * 32, hh, pix_ok, (size_t)cur.n, pix, HW, resid, out, slope_pre);
+          else if constexpr (SWAP16)
+            store_tile_swap16<MBLK * 32>(a, acc[i][b], s_epi, ml * 32, (mblk0 + ml) * 4, hh, pix_ok, (size_t)cur.n, pix, HW, resid2,
+                                         reinterpret_cast<uint4*>(out), slope_pre, zero_addr, trash_addr);
           else
             store_tile_full<MBLK * 32, PRE>(a, acc[i][b], s_epi, ml * 32, (mblk0 + ml) * 4, hh, pix_ok, (size_t)cur.n, pix, HW, resid2,
-                                            rv[PRE ? b : 0], reinterpret_cast<uint2*>(out), slope_pre);
+                                            rv[PRE ? b : 0], reinterpret_cast<uint2*>(out), slope_pre, zero_addr, trash_addr);
           __builtin_amdgcn_sched_barrier(0);     // one accumulator tile at a time (register pressure)
         }
       }
@@ -932,12 +1066,12 @@ int fill_h8(const slu_conv_h8_desc* d, H8Args& a) {
   return SLU_OK;
 }
 
-template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool SCALED, bool WRES, bool F32OUT = false>
+template <int KS, int DIL, int PAD, int MB, int WM, int WN, int RPW, bool SCALED, bool WRES, bool F32OUT = false, int KPC = 1, int OPT = 0, bool ONE = false>
 int launch_h8_k(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
   constexpr int TH = WN * RPW, MBLK = WM * MB, T = KS * KS, NWAVE = WM * WN;
   constexpr int WAVES_PER_SIMD = (MB * RPW >= 8) ? 1 : ((NWAVE >= 8 || MB >= 2 || RPW >= 2) ? 2 : 3);       // the kernel's __launch_bounds__
-  constexpr size_t nb_alloc = (size_t)((2 * (TH + 2 * PAD) * (64 + 2 * PAD) + 63) / 64) * 64;
-  const size_t lds = (size_t)3 * MBLK * 32 * 4 + (SCALED ? 2048 : 0) + 2 * nb_alloc * 16 + (size_t)MBLK * (WRES ? a.nks : 2) * T * 64 * 16;
+  constexpr size_t nb_alloc = (size_t)((KPC * 2 * (TH + 2 * PAD) * (64 + 2 * PAD) + 63) / 64) * 64;
+  const size_t lds = (size_t)3 * MBLK * 32 * 4 + (SCALED ? 2048 : 0) + 2 * nb_alloc * 16 + (size_t)MBLK * (WRES ? a.nks : 2 * KPC) * T * 64 * 16;
   if (lds > 160 * 1024) return SLU_EUNSUPPORTED;
   if (SCALED && a.Gin > 64) return SLU_EUNSUPPORTED;
   a.tiles_x = (a.W + 63) / 64;
@@ -955,7 +1089,7 @@ int launch_h8_k(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
   long long gx = (256 * per_cu + gy - 1) / gy;
   if (gx < 8) gx = 8;
   if (gx > nt) gx = nt;
-  auto kern = conv_h8_kernel<KS, DIL, PAD, MB, WM, WN, RPW, SCALED, WRES, F32OUT>;
+  auto kern = conv_h8_kernel<KS, DIL, PAD, MB, WM, WN, RPW, SCALED, WRES, F32OUT, KPC, OPT, ONE>;
   static SluLdsGrant grant;
   if (slu_grant_dynamic_lds(reinterpret_cast<const void*>(kern), lds, grant) != SLU_OK) return SLU_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64 * NWAVE), lds, st, a, d->resid, d->out);
@@ -1273,12 +1407,49 @@ int choose_h8(const H8Args& a) {
   return CFG_M32_TH4;
 }
 
+// The 8-wave 128-channel configuration (the MFMA-bound 128 / 256-channel layers of the U-Net's lower levels) with its scheduling
+// options (conv_h8_kernel's OPT / KPC).  SLU_H8_OPT / SLU_H8_KPC2 (environment) and, in -DSLU_H8_AB builds, slu_h8_dev_set_opt()
+// are A/B switches of the development tools.
+int g_h8_opt = [] { const char* e = getenv("SLU_H8_OPT"); return e ? atoi(e) : -1; }();
+int g_h8_kpc2 = [] { const char* e = getenv("SLU_H8_KPC2"); return e ? atoi(e) : H8_M128_KPC2_DEFAULT; }();
+
+constexpr size_t h8_m128_weight_bytes(int nks, int T) { return (size_t)4 * nks * T * 64 * 16; }
+
+inline bool h8_one_plain_source(const H8Args& a) { return a.nsrc == 1 && a.src[0].nb == 0 && !a.src[0].scale; }
+
+template <int KS, int DIL, int PAD, bool SCALED>
+int launch_h8_m128(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
+  if (h8_m128_weight_bytes(a.nks, KS * KS) <= WRES_MAX_BYTES) return launch_h8_k<KS, DIL, PAD, 2, 2, 4, 2, SCALED, true>(a, d, st);
+  if constexpr (!SCALED) {
+    if (h8_one_plain_source(a)) {
+      if constexpr (KS == 2) {
+        if (g_h8_kpc2 && a.nks >= 2) {
+#ifdef SLU_H8_AB
+          if (g_h8_opt == 0) return launch_h8_k<KS, DIL, PAD, 2, 2, 4, 2, false, false, false, 2, 0, true>(a, d, st);
+#endif
+          return launch_h8_k<KS, DIL, PAD, 2, 2, 4, 2, false, false, false, 2, H8_M128_OPT_2X2, true>(a, d, st);
+        }
+      }
+#ifdef SLU_H8_AB
+      switch (g_h8_opt) {
+        case 0: return launch_h8_k<KS, DIL, PAD, 2, 2, 4, 2, false, false, false, 1, 0, true>(a, d, st);
+        case 8: return launch_h8_k<KS, DIL, PAD, 2, 2, 4, 2, false, false, false, 1, 8, true>(a, d, st);
+        case 15: return launch_h8_k<KS, DIL, PAD, 2, 2, 4, 2, false, false, false, 1, 15, true>(a, d, st);
+        case 100: return launch_h8_k<KS, DIL, PAD, 2, 2, 4, 2, false, false, false, 1, 0, false>(a, d, st);      // the general form, for comparison
+      }
+#endif
+      return launch_h8_k<KS, DIL, PAD, 2, 2, 4, 2, false, false, false, 1, KS == 2 ? H8_M128_OPT_2X2 : H8_M128_OPT_3X3, true>(a, d, st);
+    }
+  }
+  return launch_h8_k<KS, DIL, PAD, 2, 2, 4, 2, SCALED, false>(a, d, st);
+}
+
 template <int KS, int DIL, int PAD, bool SCALED>
 int launch_h8_tiles(H8Args& a, const slu_conv_h8_desc* d, int cfg, hipStream_t st) {
   switch (cfg) {
     case CFG_M32_TH16: return launch_h8<KS, DIL, PAD, 1, 1, 8, 2, SCALED>(a, d, st);
     case CFG_M64_TH16: return launch_h8<KS, DIL, PAD, 2, 1, 8, 2, SCALED>(a, d, st);
-    case CFG_M128_TH8: return launch_h8<KS, DIL, PAD, 2, 2, 4, 2, SCALED>(a, d, st);
+    case CFG_M128_TH8: return launch_h8_m128<KS, DIL, PAD, SCALED>(a, d, st);
     case CFG_M32_TH8:  return launch_h8<KS, DIL, PAD, 1, 1, 4, 2, SCALED>(a, d, st);
     case CFG_M64_TH8:  return launch_h8<KS, DIL, PAD, 2, 1, 4, 2, SCALED>(a, d, st);
     case CFG_M128_TH4: return launch_h8<KS, DIL, PAD, 2, 2, 2, 2, SCALED>(a, d, st);
@@ -1407,15 +1578,31 @@ extern "C" int slu_conv2d_h8_kernel_name(const slu_conv_h8_desc* d, char* buf, s
   }
   if (ring3_name(d, a, buf, n)) return SLU_OK;
   if (a.out_f32) {
-    snprintf(buf, n, "conv_h8_kernel<1, 1, 0, 1, 1, 4, 1, false, false, true>");
+    snprintf(buf, n, "conv_h8_kernel<1, 1, 0, 1, 1, 4, 1, false, false, true, 1, 0, false>");
     return SLU_OK;
   }
-  const int* c = CFG_TABLE[choose_h8(a)];
+  const int cfg = choose_h8(a);
+  const int* c = CFG_TABLE[cfg];
   const bool wres = (size_t)c[0] * c[1] * a.nks * d->ksize * d->ksize * 64 * 16 <= WRES_MAX_BYTES;
-  snprintf(buf, n, "conv_h8_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %s, false>", d->ksize, d->dil, d->pad, c[0], c[1], c[2], c[3],
-           any_scale(d) ? "true" : "false", wres ? "true" : "false");
+  int kpc = 1, opt = 0;
+  bool one = false;
+  if (cfg == CFG_M128_TH8 && !wres && !any_scale(d) && h8_one_plain_source(a)) {      // launch_h8_m128's choice
+    one = true;
+    kpc = (d->ksize == 2 && g_h8_kpc2 && a.nks >= 2) ? 2 : 1;
+    opt = d->ksize == 2 ? H8_M128_OPT_2X2 : H8_M128_OPT_3X3;
+#ifdef SLU_H8_AB
+    if (kpc == 2 ? g_h8_opt == 0 : (g_h8_opt == 0 || g_h8_opt == 8 || g_h8_opt == 15)) opt = g_h8_opt;
+    if (kpc == 1 && g_h8_opt == 100) opt = 0, one = false;
+#endif
+  }
+  snprintf(buf, n, "conv_h8_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %s, false, %d, %d, %s>", d->ksize, d->dil, d->pad, c[0], c[1], c[2], c[3],
+           any_scale(d) ? "true" : "false", wres ? "true" : "false", kpc, opt, one ? "true" : "false");
   return SLU_OK;
 }
+
+#ifdef SLU_H8_AB
+extern "C" void slu_h8_dev_set_opt(int opt, int kpc2) { g_h8_opt = opt; g_h8_kpc2 = kpc2; }
+#endif
 
 #ifdef SLU_H8_PROF
 extern "C" int slu_h8_prof_read(unsigned long long* out8) {

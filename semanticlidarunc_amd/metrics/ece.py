@@ -33,6 +33,7 @@ class ECEAggregator:
         self.binning, self.plot_style = binning, plot_style
         self._keeps_samples = max_samples is not None or binning != "uniform"
         self._buf = CappedColumns(max_samples, seed)       # columns: confidence fp32, correct uint8 (device); sample form only
+        self._merge_seed = int(seed)
         self.reset()
 
     # the reference's attribute names, for code that inspects the aggregator
@@ -140,27 +141,37 @@ class ECEAggregator:
             return
         dev = self._merge_device
         mine = len(self._buf)
-        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-        sizes[dist.get_rank(group)] = mine
-        dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
-        seen = torch.tensor([self._buf.seen], dtype=torch.int64, device=dev)
-        dist.all_reduce(seen, op=dist.ReduceOp.SUM, group=group)
-        cap = int(sizes.max())
+        rank = dist.get_rank(group)
+        meta = torch.zeros(2, world, dtype=torch.int64, device=dev)      # row 0: reservoir sizes, row 1: pixels seen, per rank
+        meta[0, rank], meta[1, rank] = mine, self._buf.seen
+        dist.all_reduce(meta, op=dist.ReduceOp.SUM, group=group)
+        sizes, seens = meta[0].tolist(), meta[1].tolist()
+        cap = max(sizes)
         if cap == 0:
             return
-        cols = []
+        parts = []
         for ci, dt in ((0, torch.float32), (1, torch.uint8)):
             pad = torch.zeros(cap, dtype=dt, device=dev)
             if mine:
                 pad[:mine] = self._buf.columns[ci]
-            parts = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(parts, pad, group=group)
-            cols.append(torch.cat([p[:int(k)] for p, k in zip(parts, sizes.tolist())]))
-        if self.max_samples is not None and cols[0].numel() > self.max_samples:
-            pick = torch.from_numpy(self._buf.rng.choice(cols[0].numel(), size=self.max_samples, replace=False)).to(dev)
-            cols = [c[pick] for c in cols]
-        self._buf.columns, self._buf.seen = cols, int(seen.item())
+            got = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(got, pad, group=group)
+            parts.append([g[:k] for g, k in zip(got, sizes)])
+        total = sum(sizes)
+        if self.max_samples is not None and total > self.max_samples:
+            # Every rank must keep the SAME subset, and a rank's reservoir stands for the `seen` pixels it was drawn from: quotas
+            # proportional to seen (largest remainder, never more than the rank holds), indices from a generator seeded by state all
+            # ranks share -- not from the per-rank generators, which rank-specific reservoir draws have advanced differently.
+            quota = _proportional_quota(self.max_samples, seens, sizes)
+            rng = np.random.default_rng([self._merge_seed, sum(seens)] + list(sizes))
+            picks = [torch.from_numpy(np.sort(rng.choice(k, size=q, replace=False))).to(dev) for k, q in zip(sizes, quota)]
+            cols = [torch.cat([p[i] for p, i in zip(col, picks)]) for col in parts]
+        else:
+            cols = [torch.cat(col) for col in parts]
+        self._buf.columns, self._buf.seen = cols, int(sum(seens))
         self._seen = self._buf.seen
+
+    _merge_seed = 0
 
     @property
     def _merge_device(self):
@@ -215,6 +226,29 @@ class ECEAggregator:
         ax.grid(True, alpha=0.3)
         fig.tight_layout()
         return fig
+
+
+def _proportional_quota(total: int, weights, limits):
+    """Split `total` over ranks in proportion to `weights`, never above `limits`; largest remainders first, spill-over to ranks with room."""
+    n = len(weights)
+    quota = [0] * n
+    left = min(total, sum(limits))
+    active = [i for i in range(n) if limits[i] > 0 and weights[i] > 0] or [i for i in range(n) if limits[i] > 0]
+    while left > 0 and active:
+        wsum = float(sum(max(weights[i], 1) for i in active))
+        share = [left * max(weights[i], 1) / wsum for i in active]
+        give = [min(int(sh), limits[i] - quota[i]) for sh, i in zip(share, active)]
+        if sum(give) == 0:      # less than one sample each: hand out single samples by largest share
+            order = sorted(range(len(active)), key=lambda k: (-share[k], active[k]))
+            for k in order[:left]:
+                give[k] = min(1, limits[active[k]] - quota[active[k]])
+        for g, i in zip(give, active):
+            quota[i] += g
+        left -= sum(give)
+        active = [i for i in active if quota[i] < limits[i]]
+        if sum(give) == 0:
+            break
+    return quota
 
 
 # drop-in mode (this file shadows the reference's module of the same import path): names it does not define come from there

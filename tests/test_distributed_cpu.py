@@ -133,6 +133,40 @@ def _metrics_worker(rank, world, port, out):
     out.put(rank)
 
 
+def _capped_merge_worker(rank, world, port, out):
+    """Both ranks hold a full reservoir (cap 40) drawn from different amounts of evidence; their per-rank generators have been advanced
+    differently.  After the merge every rank must hold the SAME 40 samples, shared 3 : 1 like the pixels the ranks saw."""
+    from semanticlidarunc_amd.metrics.ece import ECEAggregator
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    init_from_env("gloo")
+    ece = ECEAggregator(n_bins=4, mode="probs", max_samples=40)
+    g = torch.Generator().manual_seed(7 + rank)
+    for _ in range(3 if rank == 0 else 1):                                  # rank 0 sees 300 pixels, rank 1 100
+        ece._buf.push(torch.rand(100, generator=g) * 0.5 + 0.5 * rank, torch.randint(0, 2, (100,), generator=g, dtype=torch.uint8))
+    all_reduce_metrics(None, ece, device=torch.device("cpu"))
+    conf, ok = ece._buf.columns
+    assert conf.numel() == 40 and ece._seen == 400
+    assert int((conf >= 0.5).sum()) == 10                                   # rank 1's confidences are >= 0.5: 100 / 400 of the cap
+    out.put((rank, conf.tolist(), ok.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_capped_ece_merge_is_identical_on_all_ranks_and_weighted_by_evidence():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_capped_merge_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (c, o)) for r, c, o in (out.get(timeout=240) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert got[0] == got[1]
+
+
 def test_metric_reduction_with_an_empty_rank_and_uneven_eval_shards():
     ctx = mp.get_context("spawn")
     out = ctx.Queue()

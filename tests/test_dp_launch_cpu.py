@@ -112,3 +112,27 @@ def _flat(v):
             yield from _flat(x)
     else:
         yield v
+
+
+def test_dp_launch_failing_rank_exits_without_joining_collectives(tmp_path):
+    """Rank 1 raises in its first training step while rank 0 is inside the gradient all-reduce: the failing rank must leave with a
+    non-zero code WITHOUT a barrier (which would pair with the peer's all-reduce), so the job fails fast instead of hanging."""
+    src = tmp_path / "src"
+    (src / "models").mkdir(parents=True)
+    (src / "train_like.py").write_text(textwrap.dedent(SCRIPT))
+    failing = TRAINER.replace("            self.optimizer.zero_grad()",
+                              "            if int(os.environ.get('RANK', '0')) == 1:\n                raise KeyError('unmapped label 77')\n"
+                              "            self.optimizer.zero_grad()")
+    assert failing != TRAINER
+    (src / "models" / "trainer.py").write_text(textwrap.dedent(failing))
+    cfg = tmp_path / "cfg.json"
+    cfg.write_text(json.dumps({"out_dir": str(tmp_path)}))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "tools", "dp_launch.py"), "--script", str(src / "train_like.py"), "--backend", "gloo",
+           "--cfg_path", str(cfg), "--mode", "train"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)      # a hang would hit the timeout
+    assert r.returncode != 0
+    assert "unmapped label 77" in r.stderr and "exiting without joining further collectives" in r.stderr
+    assert not (tmp_path / "rank0.json").exists() and not (tmp_path / "rank1.json").exists()

@@ -137,10 +137,18 @@ def main(argv=None):
                               cfg_path=a.cfg_path, mode=a.mode)
     try:
         mod.main(args)
-    finally:
-        if dist.is_initialized():
-            dist.barrier()
-            dist.destroy_process_group()
+    except BaseException as e:
+        # A rank that failed must NOT issue another collective: its peers are inside the gradient all-reduce (or a broadcast /
+        # buffer average), a barrier here would pair with a different-sized collective and leave the job hung until the watchdog
+        # fires.  Report and leave with a non-zero code; torch.distributed.run then tears the other ranks down.
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write(f"dp_launch: rank {rank} failed ({type(e).__name__}); exiting without joining further collectives\n")
+        sys.stderr.flush()
+        os._exit(1 if not isinstance(e, SystemExit) or e.code in (None, 0) else (e.code if isinstance(e.code, int) else 1))
+    if dist.is_initialized():      # success path only
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

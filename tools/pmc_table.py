@@ -73,6 +73,16 @@ def main():
             a["dur_us"] += sum(row["dur"]) / len(row["dur"])
             for c in counters:
                 a[c] = a.get(c, 0.0) + row.get(c, 0.0)
+        # the dispatches of the last iteration in order (bench.py maps its timed launches onto them: per-launch traffic, encoder totals)
+        disp = []
+        for k, row in rows.items():
+            if k < half:
+                continue
+            nm = re.sub(r"\(.*$", "", row["name"].replace("(anonymous namespace)::", "").replace("void ", ""))
+            d = {"name": nm, "dur_us": round(sum(row["dur"]) / len(row["dur"]), 2)}
+            for c in counters:
+                d[c] = row.get(c, 0.0)
+            disp.append(d)
         for a in agg.values():
             n = a["launches"]
             for key in list(a):
@@ -87,6 +97,7 @@ def main():
                                        f"{meta_images} 2 mc with SLU_CONV_PRECISION=f16 (the launches of one default bench.py step)",
                             "units": "FETCH_SIZE / WRITE_SIZE in KB per launch (average over the launches of the last MC step); gfx950: double "
                                      "FETCH_SIZE for 16 B/lane loads (MI355X_MICROARCH.md, HBM)"}
+        agg["_dispatches"] = disp
         with open(json_out, "w") as f:
             json.dump(agg, f, indent=1, sort_keys=True)
     print("dur_us " + " ".join(counters) + " kernel")
