@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 24
+#define SLU_ABI_VERSION 25
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -504,6 +504,35 @@ int slu_range_image_split(const float* img, const float* normals, int H, int W, 
  * xyz: fp32 [H][W][channels >= 3] (x, y, z first); normals: fp32 [H][W][3] = -(d xyz/d col x d xyz/d row) / (|.| + 1e-10) with the 3x3
  * Scharr derivatives of OpenCV (cv2.Scharr(..., scale = 1 / norm_factor), BORDER_REFLECT_101). */
 int slu_build_normals(const float* xyz, int H, int W, int channels, float norm_factor, float* normals, slu_stream_t stream);
+
+/* ---- training path of the ResNet-FPN models (SURVEY 8(a) row a3 backward, 8(b) Autograd row; models/semanticFCN.py:266-354,
+ * baselines/Reichert/semanticFCN_opt.py:366-455; trainer.py:783-786 calls loss.backward() on them): per-pixel / data-movement kernels of
+ * the autograd nodes in semanticlidarunc_amd/fpn_autograd.py.  Dense fp32 NCHW tensors, device pointers.
+ * slu_pointwise_{fwd,bwd}: op 0 = LeakyReLU(slope >= 0; 0 = nn.ReLU), 1 = tanh (AttentionModule, semanticFCN.py:32), 2 = ELU(alpha 1) + 1
+ *   (decoder_semantic + 1, :352).  The backward takes the forward's OUTPUT y: dx = dy * f'(x(y)).
+ * slu_maxpool3s2_bwd: nn.MaxPool2d(3, 2, 1) (stem, :149); the gradient goes to the FIRST maximum of a window in row-major order, as ATen does.
+ * slu_nearest_down_bwd: backward of F.interpolate(mode='nearest', scale_factor=1/factor) (:283-285): dx [N][C][H][W] from dy [N][C][H/f][W/f].
+ * slu_replace_tail_{fwd,bwd}: out = cat(x[:, :C-m], meta) (:309-313); dx (zero in the replaced channels) and / or dmeta may be NULL.
+ * slu_row_softmax_mul_bwd: out = value * softmax_W(score) (:35-38); dscore [N][1][H][W] and / or dvalue may be NULL.  W <= 4096.
+ * slu_depth_to_space_bwd: dx [N][Cout r r][H][W] from the channel slice [c_off, c_off + Cout) of dy [N][Ctot][H r][W r] (slu_depth_to_space).
+ * slu_bilinear_upsample_bwd: backward of slu_bilinear_upsample (align_corners = False); dx [N][C][H][W] from dy [N][C][H s][W s].
+ * slu_groupnorm_bwd: x, dy [N][C][HW]; mean / rstd [N groups] from slu_groupnorm_fwd; relu != 0: the forward applied ReLU and y is its output;
+ *   dgamma / dbeta: float64 [C], ADDED to (zero them first), may be NULL.
+ * slu_spatial_softmax_gate_bwd: backward of slu_spatial_softmax_gate with its stats [N][2]; workspace: float [N][HW]. */
+int slu_pointwise_fwd(const float* x, float* y, size_t n, int op, float slope, slu_stream_t stream);
+int slu_pointwise_bwd(const float* dy, const float* y, float* dx, size_t n, int op, float slope, slu_stream_t stream);
+int slu_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int N, int C, int H, int W, slu_stream_t stream);
+int slu_nearest_down_bwd(const float* dy, float* dx, int N, int C, int H, int W, int factor, slu_stream_t stream);
+int slu_replace_tail_fwd(const float* x, const float* meta, float* out, int N, int C, int m, int H, int W, slu_stream_t stream);
+int slu_replace_tail_bwd(const float* dout, float* dx, float* dmeta, int N, int C, int m, int H, int W, slu_stream_t stream);
+int slu_row_softmax_mul_bwd(const float* score, const float* value, const float* dout, float* dscore, float* dvalue, int N, int C, int H, int W,
+                            slu_stream_t stream);
+int slu_depth_to_space_bwd(const float* dy, float* dx, int N, int Cout, int H, int W, int r, int c_off, int Ctot, slu_stream_t stream);
+int slu_bilinear_upsample_bwd(const float* dy, float* dx, int N, int C, int H, int W, int scale, slu_stream_t stream);
+int slu_groupnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx,
+                      double* dgamma, double* dbeta, int N, int C, int HW, int groups, int relu, slu_stream_t stream);
+int slu_spatial_softmax_gate_bwd(const float* x, const float* score, const float* stats, const float* dout, float* dx, float* dscore,
+                                 float* workspace, int N, int C, int HW, slu_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -100,7 +100,12 @@ def torchvision_models_stub():
 
 
 # ---- functional restatement ----
+BN_TRAIN = False      # True: batch statistics (a training step's forward; the running statistics are not updated by this functional form)
+
+
 def _bn(x, sd, p):
+    if BN_TRAIN:
+        return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.0, 1e-5)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
 
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -201,6 +201,18 @@ SIGNATURES = {
                                               C.c_int, C.c_void_p, C.c_size_t, c_f32p, c_f64p, c_stream]),
     "slu_kitti_decode": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, c_f64p, C.c_void_p, c_stream]),
     "slu_range_image_split": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, c_stream]),
+    "slu_pointwise_fwd": (C.c_int, [c_f32p, c_f32p, C.c_size_t, C.c_int, C.c_float, c_stream]),
+    "slu_pointwise_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_size_t, C.c_int, C.c_float, c_stream]),
+    "slu_maxpool3s2_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_nearest_down_bwd": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_replace_tail_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_replace_tail_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_row_softmax_mul_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_depth_to_space_bwd": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_bilinear_upsample_bwd": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_groupnorm_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    c_stream]),
+    "slu_spatial_softmax_gate_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_lovasz_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_lovasz_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_size_t, c_f32p,
                                  c_f32p, c_f32p, c_stream]),

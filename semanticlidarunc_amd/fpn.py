@@ -167,9 +167,14 @@ class SemanticNetworkWithFPN(nn.Module):
             raise RuntimeError(f"semanticlidarunc_amd FPN runs on MI355X only: input is on '{x.device}' and there is no CPU fallback")
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise RuntimeError("SemanticNetworkWithFPN needs H and W divisible by 16")
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("training of the FPN model is not on the HIP path yet; call .eval() (autograd is not recorded)")
         return x.contiguous().float(), meta_channel.contiguous().float()
+
+    def _wants_autograd(self, x, meta) -> bool:
+        """The layer-by-layer autograd path (fpn_autograd.py) instead of the folded inference launches: whenever a gradient may be asked for, or
+        a BatchNorm is in train mode (batch statistics cannot be folded into the conv weights)."""
+        if any(isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training for m in self.modules()):
+            return True
+        return torch.is_grad_enabled() and (x.requires_grad or meta.requires_grad or any(p.requires_grad for p in self.parameters()))
 
     def _encode(self, x, meta):
         """(x1, x2, x3, x4): stem + the four ResNet stages with the multi-scale meta injection (semanticFCN.py:279-314)."""
@@ -325,8 +330,128 @@ class SemanticNetworkWithFPN(nn.Module):
         value = self._conv(name + ".value", att.value_conv, None, [ConvSource(x)], act="none")
         return ops.row_softmax_mul(score, value)
 
+    # ---------------- training path: one autograd node per layer (fpn_autograd.py) ----------------
+    def _dg(self, name: str) -> dict:
+        """Per-layer cache of the packed data-gradient weights (keyed by the weight's version inside ConvLayerFn)."""
+        return self.__dict__.setdefault("_dgrad_cache", {}).setdefault(name, {})
+
+    def _t_cbr(self, name, conv: nn.Conv2d, bn, srcs, resid=None, act=True):
+        """conv (stride 1) -> BatchNorm -> [+ resid] -> ReLU, the ResNet / FPN order (activation AFTER the normalisation)."""
+        from . import fpn_autograd as fa
+        y = fa.conv2d(srcs, conv.weight, conv.bias, conv.kernel_size[0], conv.padding[0], conv.dilation[0], None, bn, resid, self._dg(name))
+        return fa.relu(y) if act else y
+
+    def _t_conv_s2(self, name, conv: nn.Conv2d, bn, x):
+        """A stride-2 conv as the stride-1 conv sub-sampled (y[::2, ::2]), then BatchNorm on the sub-sampled map: 4x the conv arithmetic of
+        the strided form on these layers, but every piece (forward, data gradient, weight gradient) is the stock stride-1 kernel family."""
+        from . import fpn_autograd as fa
+        if conv.kernel_size[0] == 1:
+            y = fa.conv2d([fa.NearestDownFn.apply(x, 2)], conv.weight, conv.bias, 1, 0, 1, None, None, None, self._dg(name))
+        else:
+            full = fa.conv2d([x], conv.weight, conv.bias, conv.kernel_size[0], conv.padding[0], conv.dilation[0], None, None, None, self._dg(name))
+            y = fa.NearestDownFn.apply(full, 2)
+        return fa.batch_norm(bn, y)
+
+    def _t_stage(self, lname, layer, x, meta_k):
+        from . import fpn_autograd as fa
+        if meta_k is not None:
+            x = fa.ReplaceTailFn.apply(x, meta_k)                      # torch.cat([x[:, :-m], meta_k], 1)  (semanticFCN.py:309-313)
+        for bi, blk in enumerate(layer):
+            n = f"{lname}.{bi}"
+            if isinstance(blk, Bottleneck):
+                o = self._t_cbr(n + ".conv1", blk.conv1, blk.bn1, [x])
+                o = fa.relu(self._t_conv_s2(n + ".conv2", blk.conv2, blk.bn2, o)) if blk.stride == 2 else self._t_cbr(n + ".conv2", blk.conv2, blk.bn2, [o])
+                last, last_bn = blk.conv3, blk.bn3
+            else:
+                o = fa.relu(self._t_conv_s2(n + ".conv1", blk.conv1, blk.bn1, x)) if blk.stride == 2 else self._t_cbr(n + ".conv1", blk.conv1, blk.bn1, [x])
+                last, last_bn = blk.conv2, blk.bn2
+            idn = x
+            if blk.downsample is not None:
+                dconv, dbn = blk.downsample[0], blk.downsample[1]
+                idn = self._t_conv_s2(n + ".down", dconv, dbn, x) if dconv.stride[0] == 2 else self._t_cbr(n + ".down", dconv, dbn, [x], act=False)
+            x = self._t_cbr(n + ".tail", last, last_bn, [o], resid=idn)
+        return x
+
+    def _t_attend(self, name, att: AttentionModule, x):
+        from . import fpn_autograd as fa
+        wqk, bqk = att.query_conv.weight + att.key_conv.weight, att.query_conv.bias + att.key_conv.bias      # tanh(q + k): one conv
+        t = fa.tanh(fa.conv2d([x], wqk, bqk, 1, 0, 1, None, None, None, self._dg(name + ".qk")))
+        score = fa.conv2d([t], att.attention_conv.weight, att.attention_conv.bias, 1, 0, 1, None, None, None, self._dg(name + ".score"))
+        value = fa.conv2d([x], att.value_conv.weight, att.value_conv.bias, 1, 0, 1, None, None, None, self._dg(name + ".value"))
+        return fa.RowSoftmaxMulFn.apply(score, value)
+
+    def _t_convT_eq_stride(self, name, ct: nn.ConvTranspose2d, x):
+        """ConvTranspose2d(k = s) = 1x1 conv to Cout s s channels (+ depth-to-space by the caller); the weight re-arrangement is a
+        differentiable view of the parameter."""
+        from . import fpn_autograd as fa
+        s = ct.stride[0]
+        cin, cout = ct.weight.shape[0], ct.weight.shape[1]
+        wc = ct.weight.permute(1, 2, 3, 0).reshape(cout * s * s, cin, 1, 1)
+        b = None if ct.bias is None else ct.bias.repeat_interleave(s * s)
+        return fa.conv2d([x], wc, b, 1, 0, 1, None, None, None, self._dg(name))
+
+    def _t_convT_k4s2p1(self, name, ct: nn.ConvTranspose2d, x):
+        from . import fpn_autograd as fa
+        w = ct.weight                                            # [Cin, Cout, 4, 4]
+        cin, cout = w.shape[0], w.shape[1]
+        wf = torch.zeros((cout, 2, 2, cin, 3, 3), dtype=w.dtype, device=w.device)
+        pairs = {0: ((0, 1), (-1, 3)), 1: ((1, 0), (0, 2))}       # output parity -> ((input offset, kernel index), ...)
+        for py, ys in pairs.items():
+            for px, xs in pairs.items():
+                for dy, i in ys:
+                    for dx, j in xs:
+                        wf[:, py, px, :, dy + 1, dx + 1] = w[:, :, i, j].t()
+        b = None if ct.bias is None else ct.bias.repeat_interleave(4)
+        y = fa.conv2d([x], wf.reshape(cout * 4, cin, 3, 3), b, 3, 1, 1, None, None, None, self._dg(name))
+        return fa.depth_to_space(y, 2)
+
+    def _t_encode(self, x, meta):
+        """(x1, x2, x3, x4) of the training path: stem + the four stages with the multi-scale meta injection (semanticFCN.py:279-314)."""
+        from . import fpn_autograd as fa
+        m1 = m2 = m3 = None
+        if self.multi_scale_meta:
+            m1, m2, m3 = (fa.NearestDownFn.apply(meta, f) for f in (2, 4, 8))
+        conv1 = self.backbone.conv1                                                        # bn1 is skipped by the reference stem
+        xs = fa.conv2d([x, meta], conv1.weight, conv1.bias, 3, 1, 1, 0.0, None, None, self._dg("stem"))       # conv -> ReLU in one node
+        xs = fa.MaxPoolFn.apply(xs)
+        x1 = self._t_stage("layer1", self.layer1, xs, None)
+        x2 = self._t_stage("layer2", self.layer2, x1, m1)
+        x3 = self._t_stage("layer3", self.layer3, x2, m2)
+        x4 = self._t_stage("layer4", self.layer4, x3, m3)
+        return x1, x2, x3, x4
+
+    def _forward_train(self, x, meta):
+        from . import fpn_autograd as fa
+        from . import autograd as _ag
+        _ag.nbt_scope_enter()
+        try:
+            x1, x2, x3, x4 = self._t_encode(x, meta)
+            f4 = self._t_cbr("fpn4", self.fpn_block4[0], self.fpn_block4[1], [x4])
+            f3 = self._t_cbr("fpn3", self.fpn_block3[0], self.fpn_block3[1], [x3])
+            f2 = self._t_cbr("fpn2", self.fpn_block2[0], self.fpn_block2[1], [x2])
+            f1 = self._t_cbr("fpn1", self.fpn_block1[0], self.fpn_block1[1], [x1])
+            if self.attention:
+                f4, f3 = self._t_attend("att4", self.attention4, f4), self._t_attend("att3", self.attention3, f3)
+                f2, f1 = self._t_attend("att2", self.attention2, f2), self._t_attend("att1", self.attention1, f1)
+            u2 = self._t_convT_eq_stride("up2", self.upsample_layer_x2, f2)
+            u3 = self._t_convT_eq_stride("up3", self.upsample_layer_x3, f3)
+            u4 = self._t_convT_eq_stride("up4", self.upsample_layer_x4, f4)
+            ups = fa.DepthToSpaceCatFn.apply((self.upsample_layer_x2.stride[0], self.upsample_layer_x3.stride[0], self.upsample_layer_x4.stride[0]),
+                                             u2, u3, u4)
+            d = self.decoder_semantic
+            y = self._t_cbr("dec0", d[0], d[1], [f1, ups])
+            y = self._t_cbr("dec1", d[3], d[4], [y])
+            return fa.elu_plus_one(self._t_convT_k4s2p1("dec_out", d[6], y))
+        finally:
+            _ag.nbt_scope_exit()
+
     def forward(self, x, meta_channel):
         x, meta = self._check_inputs(x, meta_channel)
+        if self._wants_autograd(x, meta):
+            return self._forward_train(x, meta)
+        if self.backbone_name == "resnet50" and _sn.get_conv_precision() == "f16x3":
+            raise RuntimeError("models/semanticFCN with the resnet50 backbone does not run with conv precision 'f16x3': split-fp16 products miss the "
+                               "1e-3 parity bar on the 50-layer stack without GroupNorm (4e-3 of the output scale); use set_conv_precision('fp32')")
         x1, x2, x3, x4 = self._encode(x, meta)
         f4 = self._conv("fpn4", self.fpn_block4[0], self.fpn_block4[1], [ConvSource(x4)])
         f3 = self._conv("fpn3", self.fpn_block3[0], self.fpn_block3[1], [ConvSource(x3)])

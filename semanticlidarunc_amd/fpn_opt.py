@@ -114,8 +114,56 @@ class SemanticNetworkWithFPN(_FPNBase):
         """forward() with the dropout_pyramid multipliers given explicitly ([B, C_pyramid] or [B, C_pyramid, 1, 1]); parity tests."""
         return self._forward(x, meta_channel, scale)
 
+    # ---------------- training path (fpn_autograd.py nodes; trainer.py:783-786 calls loss.backward() on this model) ----------------
+    def _t_spatial_attention(self, name, att: SpatialAttention, x):
+        from . import fpn_autograd as fa
+        hid = fa.conv2d([x], att.proj.weight, None, 1, 0, 1, 0.0, None, None, self._dg(name + ".proj"))            # 1x1 -> ReLU in one node
+        score = fa.conv2d([hid], att.score.weight, None, 1, 0, 1, None, None, None, self._dg(name + ".score"))
+        return fa.SpatialGateFn.apply(x, score)
+
+    def _t_upsample_block(self, name, up: UpsampleBlock, x):
+        from . import fpn_autograd as fa
+        if up.mode != "bilinear":
+            raise NotImplementedError("UpsampleBlock: only mode='bilinear' (what the reference constructs) runs on the HIP path")
+        conv, gn = up.block[0], up.block[1]
+        y = fa.conv2d([fa.BilinearUpFn.apply(x, up.scale)], conv.weight, None, 3, 1, 1, None, None, None, self._dg(name))
+        return fa.group_norm(gn, y, relu_after=True)
+
+    def _forward_train_opt(self, x, meta, drop_scale):
+        from . import fpn_autograd as fa
+        from . import autograd as _ag
+        _ag.nbt_scope_enter()
+        try:
+            x1, x2, x3, x4 = self._t_encode(x, meta)
+            f4 = self._t_cbr("fpn4", self.fpn_block4[0], self.fpn_block4[1], [x4])
+            f3 = self._t_cbr("fpn3", self.fpn_block3[0], self.fpn_block3[1], [x3])
+            f2 = self._t_cbr("fpn2", self.fpn_block2[0], self.fpn_block2[1], [x2])
+            f1 = self._t_cbr("fpn1", self.fpn_block1[0], self.fpn_block1[1], [x1])
+            if self.attention:
+                f4, f3 = self._t_spatial_attention("att4", self.attention4, f4), self._t_spatial_attention("att3", self.attention3, f3)
+                f2, f1 = self._t_spatial_attention("att2", self.attention2, f2), self._t_spatial_attention("att1", self.attention1, f1)
+            u4 = self._t_upsample_block("up4", self.upsample_layer_x4, f4)
+            u3 = self._t_upsample_block("up3", self.upsample_layer_x3, f3)
+            u2 = self._t_upsample_block("up2", self.upsample_layer_x2, f2)
+            n = f1.shape[0]
+            c1, c2, c3, c4 = f1.shape[1], u2.shape[1], u3.shape[1], u4.shape[1]
+            s = self._pyramid_dropout(n, c1 + c2 + c3 + c4, f1.device, drop_scale)
+            u34 = fa.DepthToSpaceCatFn.apply((1, 1), u3, u4)              # channel concatenation (the fused conv takes up to three sources)
+            sc = None if s is None else (s[:, :c1].contiguous(), s[:, c1:c1 + c2].contiguous(), s[:, c1 + c2:].contiguous())
+            d = self.decoder_semantic
+            y = fa.conv2d([f1, u2, u34], d[0].weight, None, 3, 1, 1, None, None, None, self._dg("dec0"), scales=sc)
+            y = fa.group_norm(d[1], y, relu_after=True)
+            y = fa.conv2d([y], d[3].weight, None, 3, 1, 1, None, None, None, self._dg("dec1"))
+            y = fa.group_norm(d[4], y, relu_after=True)
+            y = self._t_upsample_block("dec_up", d[6], y)
+            return fa.conv2d([y], d[7].weight, d[7].bias, 1, 0, 1, None, None, None, self._dg("dec_out"))
+        finally:
+            _ag.nbt_scope_exit()
+
     def _forward(self, x, meta_channel, drop_scale):
         x, meta = self._check_inputs(x, meta_channel)
+        if self._wants_autograd(x, meta):
+            return self._forward_train_opt(x, meta, drop_scale)
         x1, x2, x3, x4 = self._encode(x, meta)
         f4 = self._conv("fpn4", self.fpn_block4[0], self.fpn_block4[1], [ConvSource(x4)])
         f3 = self._conv("fpn3", self.fpn_block3[0], self.fpn_block3[1], [ConvSource(x3)])

@@ -789,7 +789,7 @@ def bilinear_upsample(x: torch.Tensor, scale: int) -> torch.Tensor:
 
 
 def groupnorm(x: torch.Tensor, groups: int, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5, relu: bool = False,
-              inplace: bool = False) -> torch.Tensor:
+              inplace: bool = False, return_stats: bool = False):
     """nn.GroupNorm(groups, C, eps)(x) [+ ReLU] for NCHW x."""
     _req(x, "x")
     if x.dim() != 4 or x.shape[1] % int(groups):
@@ -804,10 +804,10 @@ def groupnorm(x: torch.Tensor, groups: int, gamma: Optional[torch.Tensor], beta:
     y = x if inplace else torch.empty_like(x)
     check(_lib.load().slu_groupnorm_fwd(x.data_ptr(), _ptr(gamma), _ptr(beta), n, c, h * w, int(groups), float(eps), 1 if relu else 0, stats[0].data_ptr(),
                                         stats[1].data_ptr(), y.data_ptr(), _stream()), "slu_groupnorm_fwd")
-    return y
+    return (y, stats) if return_stats else y
 
 
-def spatial_softmax_gate(x: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
+def spatial_softmax_gate(x: torch.Tensor, score: torch.Tensor, return_stats: bool = False):
     """x * softmax(score over H*W) + x  (SpatialAttention of semanticFCN_opt): x [N,C,H,W], score [N,1,H,W]."""
     _req(x, "x")
     _req(score, "score")
@@ -818,7 +818,141 @@ def spatial_softmax_gate(x: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(x)
     check(_lib.load().slu_spatial_softmax_gate(x.data_ptr(), score.data_ptr(), stats.data_ptr(), out.data_ptr(), n, c, h * w, _stream()),
           "slu_spatial_softmax_gate")
+    return (out, stats) if return_stats else out
+
+
+# ------------------------------------------------------------------------------------------------
+# training path of the FPN models (csrc/fpn_train.hip): forward / backward pieces of the autograd nodes in fpn_autograd.py
+# ------------------------------------------------------------------------------------------------
+POINTWISE_OPS = {"leaky": 0, "tanh": 1, "elu+1": 2}
+
+
+def pointwise_fwd(x: torch.Tensor, op: str, slope: float = 0.0) -> torch.Tensor:
+    """LeakyReLU(slope) (0 = ReLU) / tanh / ELU + 1, elementwise."""
+    _req(x, "x")
+    y = torch.empty_like(x)
+    if x.numel():
+        check(_lib.load().slu_pointwise_fwd(x.data_ptr(), y.data_ptr(), x.numel(), POINTWISE_OPS[op], float(slope), _stream()), "slu_pointwise_fwd")
+    return y
+
+
+def pointwise_bwd(dy: torch.Tensor, y: torch.Tensor, op: str, slope: float = 0.0) -> torch.Tensor:
+    """dx = dy * f'(x), from the forward's output y."""
+    _req(dy, "dy")
+    _req(y, "y")
+    if dy.shape != y.shape:
+        raise RuntimeError("pointwise_bwd: shape mismatch")
+    dx = torch.empty_like(dy)
+    if dy.numel():
+        check(_lib.load().slu_pointwise_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), POINTWISE_OPS[op], float(slope), _stream()),
+              "slu_pointwise_bwd")
+    return dx
+
+
+def maxpool3s2_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _req(x, "x")
+    _req(dy, "dy")
+    n, c, h, w = x.shape
+    if tuple(dy.shape) != (n, c, (h + 1) // 2, (w + 1) // 2):
+        raise RuntimeError("maxpool3s2_bwd: dy does not match the pooled shape")
+    dx = torch.empty_like(x)
+    check(_lib.load().slu_maxpool3s2_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, c, h, w, _stream()), "slu_maxpool3s2_bwd")
+    return dx
+
+
+def nearest_down_bwd(dy: torch.Tensor, factor: int) -> torch.Tensor:
+    _req(dy, "dy")
+    n, c, oh, ow = dy.shape
+    dx = torch.empty((n, c, oh * int(factor), ow * int(factor)), dtype=torch.float32, device=dy.device)
+    check(_lib.load().slu_nearest_down_bwd(dy.data_ptr(), dx.data_ptr(), n, c, oh * int(factor), ow * int(factor), int(factor), _stream()),
+          "slu_nearest_down_bwd")
+    return dx
+
+
+def replace_tail(x: torch.Tensor, meta: torch.Tensor) -> torch.Tensor:
+    """cat(x[:, :C-m], meta) with m = meta.shape[1]."""
+    _req(x, "x")
+    _req(meta, "meta")
+    n, c, h, w = x.shape
+    m = meta.shape[1]
+    if tuple(meta.shape) != (n, m, h, w) or not 0 < m <= c:
+        raise RuntimeError(f"replace_tail: x {tuple(x.shape)} / meta {tuple(meta.shape)}")
+    out = torch.empty_like(x)
+    check(_lib.load().slu_replace_tail_fwd(x.data_ptr(), meta.data_ptr(), out.data_ptr(), n, c, m, h, w, _stream()), "slu_replace_tail_fwd")
     return out
+
+
+def replace_tail_bwd(dout: torch.Tensor, m: int, want_dx: bool = True, want_dmeta: bool = True):
+    _req(dout, "dout")
+    n, c, h, w = dout.shape
+    dx = torch.empty_like(dout) if want_dx else None
+    dmeta = torch.empty((n, m, h, w), dtype=torch.float32, device=dout.device) if want_dmeta else None
+    if want_dx or want_dmeta:
+        check(_lib.load().slu_replace_tail_bwd(dout.data_ptr(), _ptr(dx), _ptr(dmeta), n, c, int(m), h, w, _stream()), "slu_replace_tail_bwd")
+    return dx, dmeta
+
+
+def row_softmax_mul_bwd(score, value, dout, want_dscore: bool = True, want_dvalue: bool = True):
+    _req(score, "score")
+    _req(value, "value")
+    _req(dout, "dout")
+    n, c, h, w = value.shape
+    if tuple(score.shape) != (n, 1, h, w) or dout.shape != value.shape:
+        raise RuntimeError("row_softmax_mul_bwd: shape mismatch")
+    dscore = torch.empty_like(score) if want_dscore else None
+    dvalue = torch.empty_like(value) if want_dvalue else None
+    if want_dscore or want_dvalue:
+        check(_lib.load().slu_row_softmax_mul_bwd(score.data_ptr(), value.data_ptr(), dout.data_ptr(), _ptr(dscore), _ptr(dvalue), n, c, h, w, _stream()),
+              "slu_row_softmax_mul_bwd")
+    return dscore, dvalue
+
+
+def depth_to_space_bwd(dy: torch.Tensor, cout: int, r: int, c_off: int = 0) -> torch.Tensor:
+    """Gradient of depth_to_space w.r.t. its input from the channel slice [c_off, c_off + cout) of dy [N,Ctot,H*r,W*r]."""
+    _req(dy, "dy")
+    n, ctot, oh, ow = dy.shape
+    if oh % r or ow % r or c_off < 0 or c_off + cout > ctot:
+        raise RuntimeError("depth_to_space_bwd: shape mismatch")
+    dx = torch.empty((n, cout * r * r, oh // r, ow // r), dtype=torch.float32, device=dy.device)
+    check(_lib.load().slu_depth_to_space_bwd(dy.data_ptr(), dx.data_ptr(), n, int(cout), oh // r, ow // r, int(r), int(c_off), ctot, _stream()),
+          "slu_depth_to_space_bwd")
+    return dx
+
+
+def bilinear_upsample_bwd(dy: torch.Tensor, scale: int) -> torch.Tensor:
+    _req(dy, "dy")
+    n, c, oh, ow = dy.shape
+    if oh % scale or ow % scale:
+        raise RuntimeError("bilinear_upsample_bwd: shape mismatch")
+    dx = torch.empty((n, c, oh // scale, ow // scale), dtype=torch.float32, device=dy.device)
+    check(_lib.load().slu_bilinear_upsample_bwd(dy.data_ptr(), dx.data_ptr(), n, c, oh // scale, ow // scale, int(scale), _stream()),
+          "slu_bilinear_upsample_bwd")
+    return dx
+
+
+def groupnorm_bwd(x, y, dy, gamma, stats, groups: int, relu: bool, want_affine: bool = True):
+    """(dx, dgamma f64[C] | None, dbeta f64[C] | None); stats = the [2, N*groups] (mean, rstd) tensor of groupnorm(return_stats=True)."""
+    _req(x, "x")
+    _req(dy, "dy")
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    dg = zeros_f64((c,), x.device) if want_affine else None
+    db = zeros_f64((c,), x.device) if want_affine else None
+    check(_lib.load().slu_groupnorm_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), _ptr(gamma), stats[0].data_ptr(), stats[1].data_ptr(), dx.data_ptr(),
+                                        _ptr(dg), _ptr(db), n, c, h * w, int(groups), 1 if relu else 0, _stream()), "slu_groupnorm_bwd")
+    return dx, dg, db
+
+
+def spatial_softmax_gate_bwd(x, score, stats, dout):
+    _req(x, "x")
+    _req(score, "score")
+    _req(dout, "dout")
+    n, c, h, w = x.shape
+    dx, dscore = torch.empty_like(x), torch.empty_like(score)
+    ws = torch.empty((n, h * w), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_spatial_softmax_gate_bwd(x.data_ptr(), score.data_ptr(), stats.data_ptr(), dout.data_ptr(), dx.data_ptr(), dscore.data_ptr(),
+                                                   ws.data_ptr(), n, c, h * w, _stream()), "slu_spatial_softmax_gate_bwd")
+    return dx, dscore
 
 
 # ------------------------------------------------------------------------------------------------

@@ -96,8 +96,17 @@ def test_strided_and_transposed_convs_as_fused_launches(cuda, prec):
     ("resnet50_m3_c5", dict(backbone="resnet50", input_channels=2, meta_channel_dim=3, num_classes=5))])      # Bottleneck blocks, 2048..128 ladder
 def test_fpn_matches_reference_golden(cuda, prec, tag, kw):
     if prec == "f16x3" and "resnet50" in tag:
-        pytest.skip("split-fp16 products: 4e-3 of the output scale on this fixture (activations of the 50-layer stack with randomised BatchNorm "
-                    "leave the range where fp16 hi + lo carries 22 bits); the exact-fp32 path is the one pinned for resnet50")
+        # split-fp16 products are 4e-3 of the output scale on this fixture (the activations of the 50-layer stack without GroupNorm leave the
+        # range where fp16 hi + lo carries 22 bits): the plain FPN class REFUSES that precision for resnet50 instead of running out of the bar
+        model = SemanticNetworkWithFPN(**kw).to(cuda).eval()
+        sn.set_conv_precision(prec)
+        try:
+            with pytest.raises(RuntimeError, match="f16x3"):
+                with torch.no_grad():
+                    model(torch.zeros(1, 2, 32, 64, device=cuda), torch.zeros(1, 3, 32, 64, device=cuda))
+        finally:
+            sn.set_conv_precision("fp32")
+        return
     g = golden("fpn_" + tag)
     torch.manual_seed(0)
     model = randomize_bn_(SemanticNetworkWithFPN(**kw), 3).eval()
