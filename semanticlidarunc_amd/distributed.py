@@ -56,6 +56,7 @@ class FlatGradAllReduce:
             self.offsets.append(n)
             n += p.numel()
         self.flat = torch.zeros(n, dtype=dt, device=dev)
+        self._events = []
 
     @property
     def nbytes(self) -> int:
@@ -63,23 +64,45 @@ class FlatGradAllReduce:
 
     @torch.no_grad()
     def reduce(self) -> None:
+        """ONE collective per step: the gradients are packed into the flat buffer by one multi-tensor copy, summed over the ranks by one
+        all-reduce, scaled once, and handed back as VIEWS of the flat buffer (no copy back: `optimizer.step()` reads `p.grad` right after this
+        hook; the next `zero_grad()` drops or zeroes the views).  `timed = True` brackets the collective with events (`last_allreduce_ms`)."""
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1:
             return
+        segs, grads = [], []
         for p, o in zip(self.params, self.offsets):
             seg = self.flat[o:o + p.numel()]
             if p.grad is None:
                 seg.zero_()
-            else:
-                seg.copy_(p.grad.reshape(-1))
+            elif p.grad.data_ptr() != seg.data_ptr():          # (already a view of the buffer when zero_grad(set_to_none=False) kept it)
+                segs.append(seg)
+                grads.append(p.grad.reshape(-1))
+        if segs:
+            torch._foreach_copy_(segs, grads)
+        ev = None
+        if self.timed and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
         self.flat.mul_(1.0 / world)
         for p, o in zip(self.params, self.offsets):
-            g = self.flat[o:o + p.numel()].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        self.calls += 1
+
+    timed = False
+    calls = 0
+
+    @property
+    def last_allreduce_ms(self):
+        """Mean duration of the timed all-reduces so far (synchronises), or None."""
+        if not getattr(self, "_events", None):
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._events) / len(self._events)
 
     def attach_to_optimizer(self, optimizer: torch.optim.Optimizer):
         """optimizer.step() now all-reduces first; returns the hook handle."""

@@ -51,7 +51,16 @@ def _worker(rank, world, port, out):
     loss = (model[:4](x_all[idx]) - y_all[idx]).square().mean()
     opt.zero_grad()
     loss.backward()
-    opt.step()                                        # hook all-reduces, then identical update everywhere
+    calls = []
+    real_all_reduce = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), real_all_reduce(*a, **k))[1]
+    try:
+        opt.step()                                    # hook all-reduces, then identical update everywhere
+    finally:
+        dist.all_reduce = real_all_reduce
+    assert calls == [red.flat.numel()] and red.calls == 1          # exactly ONE collective, over the whole flat buffer
+    for p_, o in zip(red.params, red.offsets):                      # the averaged gradients are views of that buffer (no copy back)
+        assert p_.grad.data_ptr() == red.flat[o:o + p_.numel()].data_ptr()
     # single-process reference on the union of both shards
     other = list(iter(ShardedSampler(8, 1 - rank, world, seed=3)))
     assert sorted(idx + other) == list(range(8))

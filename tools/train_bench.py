@@ -32,6 +32,7 @@ def measure(dev, batch=4, steps=5, warmup=2, height=64, width=2048, precision="f
         broadcast_parameters(model)
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, capturable=graph)
         red = FlatGradAllReduce(model.parameters())
+        red.timed = world > 1
         if not graph:
             red.attach_to_optimizer(opt)
         x, y = synthetic_scan(batch, height, width, seed=1234 + rank)
@@ -78,7 +79,11 @@ def measure(dev, batch=4, steps=5, warmup=2, height=64, width=2048, precision="f
                 "steps": steps, "warmup": warmup,
                 "dtype": "f32" if precision == "fp32" else "f32 storage + accumulate, f16x3 products in the forward convs; exact f32 dgrad / wgrad",
                 "conv_tflops_per_gpu(3x fwd flops)": round(tf, 2), "frac_fp32_mfma_peak": round(tf / 157.3, 4), "loss": round(float(loss), 5),
-                "grad_allreduce_mb": round(red.nbytes / 1e6, 1), "hip_graph": bool(graph)}
+                "grad_allreduce_mb": round(red.nbytes / 1e6, 1),
+                "grad_allreduce_ms": None if red.last_allreduce_ms is None else round(red.last_allreduce_ms, 3),
+                "grad_allreduce": "one flat fp32 RCCL all-reduce per step from an optimizer pre-step hook (gradients packed by one multi-tensor copy, "
+                                  "handed back as views of the flat buffer)" if world > 1 else "single rank: no collective",
+                "hip_graph": bool(graph)}
     finally:
         sn.set_train_conv_precision(prev)
 
