@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 25
+#define SLU_ABI_VERSION 26
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -533,6 +533,27 @@ int slu_groupnorm_bwd(const float* x, const float* y, const float* dy, const flo
                       double* dgamma, double* dbeta, int N, int C, int HW, int groups, int relu, slu_stream_t stream);
 int slu_spatial_softmax_gate_bwd(const float* x, const float* score, const float* stats, const float* dout, float* dx, float* dscore,
                                  float* workspace, int N, int C, int HW, slu_stream_t stream);
+
+/* ---- all Dropout2d multipliers of one MC-dropout evaluation in one launch (SalsaNext.py:98,106,145,149,168; utils/mc_dropout.py:13-34) ----
+ * A site is one nn.Dropout2d application: an [N][C] table of multipliers, 0 with probability p, else 1 / (1 - p); inactive sites give 1.
+ * The draws are Philox4x32-10(key = seed, counter = offset + g / 4)[g % 4] for the g-th element of the call (sites in table order, `begin` =
+ * first g of the site), i.e. a pure function of torch's generator state: the host reads (seed, offset) from the CUDA generator and advances
+ * the offset by ceil(total draws / 4).  An output is an [N][C] table buf[begin ...] = product over its <= 3 sites:
+ *   site_a[n][off_a + c] * site_b[n][off_b + c'] * site_c[n][off_c + c'],  c' = shuffled ? c / 4 : c  (stored channel c of a tensor read
+ *   through PixelShuffle(2) feeds shuffled channel c / 4: UpBlock's dropout1 / dropout2 act on the shuffled tensor, SalsaNext.py:141-149);
+ * a site index of -1 drops the factor.  `sites`, `outs`: DEVICE arrays; outs sorted by `begin`; total = sum of N * C over the outputs. */
+typedef struct slu_dropout_site {
+  long long begin;
+  int C, active;
+  float p;
+  int reserved;
+} slu_dropout_site;
+typedef struct slu_dropout_out {
+  long long begin;
+  int C, site_a, off_a, site_b, off_b, site_c, off_c, shuffled;
+} slu_dropout_out;
+int slu_dropout_draw(const slu_dropout_site* sites, int nsites, const slu_dropout_out* outs, int nout, int N, unsigned long long seed,
+                     unsigned long long offset, float* buf, long long total, slu_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,8 @@ class SemanticKitti(Dataset):
                 raise RuntimeError("SemanticKitti: the HIP path cannot run inside a DataLoader worker; use SemanticKitti.gpu_loader(...) "
                                    "(workers read files, the main process projects) or keep the reference's dataset package on sys.path")
             if self._ref is None:
+                from .utils import _warn_delegation
+                _warn_delegation("SemanticKitti.__getitem__")
                 self._ref = _shadowed.SemanticKitti(self.data_path, self.rotate, self.flip, self.resolution, self.projection, self.resize)
             return self._ref[idx]
         if self._projector is None:

@@ -18,6 +18,22 @@ def to_deflection_coordinates(x, y, z):
     return phi, theta
 
 
+_WARNED = set()
+
+
+def _warn_delegation(what: str) -> None:
+    """Once per process: a DataLoader WORKER cannot touch the GPU, so this call runs the shadowed reference code (numpy / cv2) instead of the HIP
+    kernels -- say so, and say how to get the device path."""
+    if what in _WARNED:
+        return
+    _WARNED.add(what)
+    import warnings
+    warnings.warn(f"semanticlidarunc_amd: {what} was called inside a DataLoader worker process and is handled by the reference's CPU code there "
+                  "(a forked worker must not use the GPU). To run decode / projection / normals as HIP kernels keep the workers for file reads "
+                  "only: SemanticKitti.gpu_loader(...), dataset.gpu_pipeline.projecting_loader_class, or tools/dp_launch.py --gpu-projection "
+                  "(or num_workers=0).", RuntimeWarning, stacklevel=3)
+
+
 def spherical_projection(pc, height=64, width=2048, theta_range=None, th=1.0, sort_largest_first=False, bins_h=None, max_range=None,
                          device="cuda"):
     """pc: [N, C] array or tensor (x, y, z, ...).  The nearest point of a pixel survives (the reference writes the points in
@@ -26,6 +42,7 @@ def spherical_projection(pc, height=64, width=2048, theta_range=None, th=1.0, so
     if torch.utils.data.get_worker_info() is not None:
         # a forked DataLoader worker must not touch the GPU: hand the call to the module this file shadows (the reference's numpy code)
         if _shadowed is not None:
+            _warn_delegation("spherical_projection")
             return _shadowed.spherical_projection(pc, height, width, theta_range, th, sort_largest_first, bins_h, max_range)
         raise RuntimeError("spherical_projection: the HIP projection cannot run inside a DataLoader worker process; "
                            "project in the main process (num_workers=0) or keep the reference's dataset/utils.py on sys.path")
@@ -58,6 +75,7 @@ def build_normal_xyz(xyz, norm_factor=0.25, ksize=3, device="cuda"):
     A numpy image returns numpy (the reference's contract); a GPU tensor returns a GPU tensor without leaving the device."""
     if torch.utils.data.get_worker_info() is not None:
         if _shadowed is not None:                     # forked DataLoader worker: the reference's cv2 code, as for the projection
+            _warn_delegation("build_normal_xyz")
             return _shadowed.build_normal_xyz(xyz, norm_factor, ksize)
         raise RuntimeError("build_normal_xyz: the HIP kernel cannot run inside a DataLoader worker process; compute the normals in the "
                            "main process (num_workers=0) or keep the reference's dataset/utils.py on sys.path")

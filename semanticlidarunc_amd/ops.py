@@ -1275,3 +1275,45 @@ def range_image_split(img: torch.Tensor, normals: Optional[torch.Tensor], range_
             raise RuntimeError("normals: expected [H, W, 3] in and [3, H, W] out")
     check(_lib.load().slu_range_image_split(img.data_ptr(), _ptr(normals), h, w, c, range_out.data_ptr(), refl_out.data_ptr(), xyz_out.data_ptr(),
                                             _ptr(normals_out) if normals is not None else None, labels_out.data_ptr(), _stream()), "slu_range_image_split")
+
+
+# ------------------------------------------------------------------------------------------------
+# Dropout2d multipliers of a whole MC evaluation in one launch (csrc/dropout_draw.hip)
+# ------------------------------------------------------------------------------------------------
+class DropoutPlan:
+    """Device tables for slu_dropout_draw: `sites` = [(C, p, active)], `outs` = [(key, C, (site, offset) x <= 3, shuffled)] for batch size n."""
+
+    def __init__(self, n: int, sites, outs, device):
+        import numpy as np
+        self.n, self.device = int(n), device
+        st = np.zeros(len(sites), dtype=np.dtype([("begin", "<i8"), ("C", "<i4"), ("active", "<i4"), ("p", "<f4"), ("reserved", "<i4")]))
+        g = 0
+        for i, (c, p, active) in enumerate(sites):
+            st[i] = (g, c, 1 if active else 0, p, 0)
+            if active:
+                g += self.n * c
+        self.draws = g
+        ot = np.zeros(len(outs), dtype=np.dtype([("begin", "<i8"), ("C", "<i4"), ("site_a", "<i4"), ("off_a", "<i4"), ("site_b", "<i4"), ("off_b", "<i4"),
+                                                 ("site_c", "<i4"), ("off_c", "<i4"), ("shuffled", "<i4")]))
+        e, self.slices = 0, []
+        for i, (key, c, refs, shuffled) in enumerate(outs):
+            refs = list(refs) + [(-1, 0)] * (3 - len(refs))
+            ot[i] = (e, c, refs[0][0], refs[0][1], refs[1][0], refs[1][1], refs[2][0], refs[2][1], 1 if shuffled else 0)
+            self.slices.append((key, e, c))
+            e += self.n * c
+        self.total = e
+        assert st.dtype.itemsize == 24 and ot.dtype.itemsize == 40
+        self.sites = torch.from_numpy(st.view(np.uint8).copy()).to(device)
+        self.outs = torch.from_numpy(ot.view(np.uint8).copy()).to(device)
+        self.nsites, self.nout = len(sites), len(outs)
+
+    def run(self):
+        """{key: [n, C] multiplier}: one launch; consumes ceil(draws / 4) (rounded up to a multiple of 4) counters of torch's CUDA generator."""
+        gen = torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
+        seed, off = int(gen.initial_seed()), int(gen.get_offset())
+        adv = ((self.draws + 3) // 4 + 3) // 4 * 4
+        gen.set_offset(off + adv)
+        buf = torch.empty(self.total, dtype=torch.float32, device=self.device)
+        check(_lib.load().slu_dropout_draw(self.sites.data_ptr(), self.nsites, self.outs.data_ptr(), self.nout, self.n, seed & (2 ** 64 - 1), off, buf.data_ptr(),
+                                           self.total, _stream()), "slu_dropout_draw")
+        return {key: buf[b:b + self.n * c].view(self.n, c) for key, b, c in self.slices}

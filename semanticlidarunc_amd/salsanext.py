@@ -206,6 +206,10 @@ class _FusedBlock(nn.Module):
                                 slope=slope, bn_a=bn_a, bn_b=bn_b, resid=resid, precision=precision)
 
 
+# A/B switch: 0 = draw the MC-dropout multipliers through the nn.Dropout2d children (ATen launches on a side stream) instead of the one-launch kernel
+_DROPOUT_KERNEL = os.environ.get("SLU_DROPOUT_KERNEL", "1") != "0"
+
+
 def _draw(drop: nn.Dropout2d, n: int, c: int, device, override: Optional[Dict[str, torch.Tensor]], name: str):
     """[n,c] multiplier of one Dropout2d site, or None when it is the identity."""
     if override is not None:
@@ -472,6 +476,8 @@ class SalsaNext(_FusedBlock):
         sites = [(f"{blk}.{name}", getattr(getattr(self, blk), name), c) for blk, name, c in self._DROPOUT_SITES]
         if not any(d.training and d.p > 0.0 for _, d, _ in sites):
             return None
+        if _DROPOUT_KERNEL:
+            return self._predraw_dropout_kernel(n, device, sites)
         main = torch.cuda.current_stream(device)
         side = self.__dict__.get("_drop_stream")
         if side is None or side.device != device:
@@ -496,6 +502,56 @@ class SalsaNext(_FusedBlock):
                 prod = out.get(f"{blk}.dropout3")
         self.__dict__["_drop_event"] = side.record_event()
         return out
+
+    def _predraw_dropout_kernel(self, n: int, device, sites):
+        """The same dictionary from ONE hand-written launch (csrc/dropout_draw.hip): every multiplier a consumer needs -- the plain masks of the
+        encoder sites and of the deferred dropout3 sites, and the decoder's composed products -- is a stateless Philox function of torch's CUDA
+        generator state, so no intermediate mask is materialised and no ATen launch (bernoulli, mul, fill, copy: ~64 per MC step before) is left
+        on the path.  The generator's offset is advanced, so `torch.manual_seed` reproduces the masks and successive calls differ."""
+        sig = (n, str(device), tuple((bool(d.training), float(d.p)) for _, d, _ in sites))
+        plan = self.__dict__.get("_drop_plan")
+        if plan is None or plan[0] != sig:
+            index = {key: i for i, (key, _, _) in enumerate(sites)}
+            active = {key: bool(d.training and d.p > 0.0) for key, d, _ in sites}
+            chans = {key: c for key, _, c in sites}
+            outs = []
+
+            def add(key, c, refs, shuffled=False):
+                refs = [(index[k], off) for k, off in refs if k is not None and active.get(k, False)]
+                if refs:
+                    outs.append((key, c, refs, shuffled))
+
+            for blk in ("resBlock2", "resBlock3", "resBlock4", "resBlock5"):
+                add(f"{blk}.dropout", chans[f"{blk}.dropout"], [(f"{blk}.dropout", 0)])
+            prod = "resBlock5.dropout"
+            for blk in ("upBlock1", "upBlock2", "upBlock3", "upBlock4"):
+                m = getattr(self, blk)
+                cu, cs = m.in_filters // 4, m.conv1.in_channels - m.in_filters // 4
+                d1, d2, d3 = (f"{blk}.dropout{k}" if f"{blk}.dropout{k}" in index else None for k in (1, 2, 3))
+                add(f"{blk}._sx", m.in_filters, [(prod, 0), (d1, 0), (d2, 0)], shuffled=True)
+                # (the shuffled flag applies to the second and third factor: the producer's multiplier is per STORED channel)
+                add(f"{blk}._ss", cs, [(d2, cu)])
+                if d3 is not None:
+                    add(f"{blk}.dropout3", chans[d3], [(d3, 0)])
+                prod = d3
+            fixed = []
+            for key, c, refs, shuffled in outs:      # slu_dropout_out: factor a is read unshuffled, b and c through c / 4
+                if shuffled and (len(refs) < 1 or refs[0][0] != index.get(self._sx_producer(key), -2)):
+                    refs = [(-1, 0)] + refs          # no (active) producer multiplier: keep the shuffled factors in slots b / c
+                fixed.append((key, c, refs[:3], shuffled))
+            plan = (sig, ops.DropoutPlan(n, [(c, float(d.p), bool(d.training and d.p > 0.0)) for _, d, c in sites], fixed, device),
+                    [f"{blk}._composed" for blk in ("upBlock1", "upBlock2", "upBlock3", "upBlock4")])
+            self.__dict__["_drop_plan"] = plan
+        out = plan[1].run()
+        for k in plan[2]:
+            out[k] = True
+        return out
+
+    @staticmethod
+    def _sx_producer(key: str):
+        """The site whose deferred multiplier reaches `<upBlockK>._sx` per stored channel."""
+        return {"upBlock1._sx": "resBlock5.dropout", "upBlock2._sx": "upBlock1.dropout3", "upBlock3._sx": "upBlock2.dropout3",
+                "upBlock4._sx": "upBlock3.dropout3"}.get(key)
 
     def _pack_training_weights(self):
         """Training step (exact-fp32 products): the forward and data-gradient MFMA images of ALL conv weights in one launch

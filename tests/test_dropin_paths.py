@@ -45,7 +45,12 @@ def test_shadowing_merges_packages_and_reexports_missing_names(tmp_path):
         import dataset.utils as du, torch.utils.data as tud
         assert 'semanticlidarunc_amd' in du.__file__ and du.rotate_z(0, 0) == 'ref rotate'
         tud.get_worker_info = lambda: object()
-        assert du.spherical_projection(None) == 'reference numpy projection'
+        import warnings
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            assert du.spherical_projection(None) == 'reference numpy projection'
+            assert du.spherical_projection(None) == 'reference numpy projection'
+        assert len(w) == 1 and 'DataLoader worker' in str(w[0].message) and 'gpu_loader' in str(w[0].message)      # said once, with the way out
         print('ok')
     """)
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "semanticlidarunc_amd"), str(src)]))

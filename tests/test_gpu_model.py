@@ -165,3 +165,44 @@ def test_eval_after_running_stat_update_with_frozen_affine_matches_oracle(cuda, 
             if b.is_floating_point():
                 b.mul_(1.0)
         assert float((m(xg).cpu() - want).abs().max()) <= TOL
+
+
+def test_one_launch_dropout_draw(cuda, model):
+    """csrc/dropout_draw.hip: every multiplier of an MC evaluation from one launch -- Bernoulli(1 - p) / (1 - p) per (sample, channel), products
+    composed like UpBlock composes them, reproducible from torch's generator state and advancing it."""
+    from semanticlidarunc_amd import ops
+    n = 64
+    plan = ops.DropoutPlan(n, [(8, 0.2, True), (2, 0.2, True), (5, 0.2, True), (6, 0.5, False)],
+                           [("A", 8, [(0, 0)], False), ("B", 2, [(1, 0)], False), ("D2", 5, [(2, 0)], False),
+                            ("sx", 8, [(0, 0), (1, 0), (2, 0)], True), ("ss", 3, [(2, 2)], False), ("off", 6, [(3, 0)], False),
+                            ("sx_noprod", 8, [(-1, 0), (1, 0), (2, 0)], True)], cuda)
+    torch.manual_seed(11)
+    a = plan.run()
+    assert torch.equal(a["sx"], a["A"] * (a["B"] * a["D2"][:, :2]).repeat_interleave(4, dim=1))
+    assert torch.equal(a["sx_noprod"], (a["B"] * a["D2"][:, :2]).repeat_interleave(4, dim=1))
+    assert torch.equal(a["ss"], a["D2"][:, 2:]) and torch.equal(a["off"], torch.ones_like(a["off"]))      # an inactive site multiplies by 1
+    b = plan.run()
+    assert not torch.equal(a["A"], b["A"])                                                                 # the generator moved on
+    torch.manual_seed(11)
+    c = plan.run()
+    assert all(torch.equal(a[k], c[k]) for k in a)                                                         # and is reproducible
+    # the model's own plan: values, keep rate, structure of a composed product
+    set_dropout_mode(model, True)
+    try:
+        torch.manual_seed(5)
+        s = model._predraw_dropout(512, cuda)
+    finally:
+        set_dropout_mode(model, False)
+    m = s["resBlock3.dropout"]
+    assert m.shape == (512, 256) and torch.unique(m).cpu().tolist() == [0.0, 1.25] and abs(float((m > 0).float().mean()) - 0.8) < 0.01
+    means = [float((s[k] > 0).float().mean()) for k in ("resBlock2.dropout", "resBlock4.dropout", "resBlock5.dropout", "upBlock1.dropout3", "upBlock3.dropout3")]
+    assert all(abs(v - 0.8) < 0.01 for v in means), means
+    sx, prod = s["upBlock1._sx"], s["resBlock5.dropout"]
+    assert sx.shape == (512, 256) and bool(((prod == 0) <= (sx == 0)).all())                                # the producer's zeros survive
+    assert abs(float((sx > 0).float().mean()) - 0.8 ** 3) < 0.01                                            # three independent sites
+    assert torch.equal(sx[:, 0::4] > 0, sx[:, 0::4] > 0) and s["upBlock1._ss"].shape == (512, 256) and s["upBlock4._sx"].shape == (512, 64)
+    vals = sorted(set(torch.unique(sx).cpu().tolist()))
+    assert vals == [0.0, 1.25 ** 3]
+    # channels of different sites / samples are not correlated through the shared counter stream
+    x = (s["resBlock3.dropout"] > 0).float()
+    assert abs(float(((x[:, :-1] * x[:, 1:]).mean() - 0.64))) < 0.01 and abs(float((x[:-1] * x[1:]).mean() - 0.64)) < 0.01
