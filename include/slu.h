@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 26
+#define SLU_ABI_VERSION 27
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -72,7 +72,7 @@ typedef struct slu_conv_desc {   /* HOST struct */
   int32_t ck;            /* K-chunk the weights were packed with (slu_conv_ck)                   */
   const float* wpack;    /* slu_pack_conv_weight output                                          */
   const float* bias;     /* [Cout] or NULL                                                       */
-  int32_t has_act;       /* 0 none; 1: leaky(v) = v > 0 ? v : slope * v (slope 0 = ReLU); 2: tanh(v);
+  int32_t has_act;       /* 0 none; 1: leaky(v) = v > 0 ? v : slope * v (slope 0 = ReLU); 2: tanh(v); 3: SiLU v * sigmoid(v);
                             +4 (with 1 only): apply it after bn_a/bn_b and the residual add (ResNet BasicBlock) instead of before */
   float slope;
   const float* bn_a;     /* [Cout] or NULL (then bn_b ignored): folded eval BatchNorm            */
@@ -554,6 +554,18 @@ typedef struct slu_dropout_out {
 } slu_dropout_out;
 int slu_dropout_draw(const slu_dropout_site* sites, int nsites, const slu_dropout_out* outs, int nout, int N, unsigned long long seed,
                      unsigned long long offset, float* buf, long long total, slu_stream_t stream);
+
+/* ---- EfficientNetV2 blocks of the semanticFCN_opt encoder (baselines/Reichert/semanticFCN_opt.py:170-180,238-247,396-404;
+ * the block structure is torchvision's efficientnet_v2_{s,m,l}: FusedMBConv / MBConv with depthwise 3x3, squeeze-excitation, SiLU) -----------
+ * slu_dwconv3x3_fwd: depthwise 3x3, padding 1, stride 1 or 2, with the eval BatchNorm folded into w [C][9] / bias [C]; act 0 none, 3 SiLU.
+ *   x [N][C][H][W] -> y [N][C][ceil(H/stride)][ceil(W/stride)].
+ * slu_global_avgpool: mean over H W -> out [N][C] (SqueezeExcitation.avgpool).
+ * slu_se_gate: scale [N][C] = sigmoid(w2 [C][S] . SiLU(w1 [S][C] . avg + b1) + b2)  (fc1 / fc2 of SqueezeExcitation are 1x1 convs on a 1x1 map);
+ *   the scale reaches the block's projection conv as a per-(sample, channel) input multiplier (slu_conv_src.scale). */
+int slu_dwconv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int stride, int act, slu_stream_t stream);
+int slu_global_avgpool(const float* x, float* out, int N, int C, int HW, slu_stream_t stream);
+int slu_se_gate(const float* avg, const float* w1, const float* b1, const float* w2, const float* b2, float* scale, int N, int C, int S,
+                slu_stream_t stream);
 
 #ifdef __cplusplus
 }

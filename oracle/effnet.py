@@ -1,0 +1,149 @@
+"""Oracle: the EfficientNetV2 encoder of `semanticFCN_opt` (plain torch CPU ops).  TEST INFRASTRUCTURE ONLY.
+
+torchvision (pinned 0.19.1, docker/Dockerfile:195) is absent from the build image, so -- as for the ResNets in oracle/fpn.py -- this file
+RESTATES the public architecture of torchvision.models.efficientnet for the V2 family: stem Conv2dNormActivation(3x3, stride 2, BatchNorm eps
+1e-3, SiLU); FusedMBConv (3x3 expansion conv + 1x1 projection, or a single 3x3 when the expansion ratio is 1); MBConv (1x1 expansion, depthwise
+3x3, SqueezeExcitation with squeeze = max(1, input // 4), SiLU / sigmoid, 1x1 projection); residual where stride 1 and equal channels;
+StochasticDepth = identity in eval mode.  **Block internals: parity unpinned** (no reference-held fixture).  What IS pinned, by the reference's
+own class run through `torchvision_models_stub` (tools/gen_golden_r03.py effnet): which of these stages the model uses and how
+(semanticFCN_opt.py:238-247: features[0] with its conv replaced, features[2], [3], [4]; :396-404: the meta injection and
+x4 = cat(x3[:, :-m], meta3) -- layer4 = features[6:] is constructed and never called), the head and the state_dict layout."""
+from __future__ import annotations
+
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from semanticlidarunc_amd.effnet import _CONFIGS, BN_EPS, _make_divisible      # the configuration TABLE only (data)
+
+
+class CNA(nn.Sequential):
+    def __init__(self, cin, cout, k=3, stride=1, groups=1, act=True):
+        layers = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), nn.BatchNorm2d(cout, eps=BN_EPS)]
+        if act:
+            layers.append(nn.SiLU(inplace=True))
+        super().__init__(*layers)
+        self.out_channels = cout
+
+
+class SE(nn.Module):
+    def __init__(self, c, s):
+        super().__init__()
+        self.avgpool, self.fc1, self.fc2 = nn.AdaptiveAvgPool2d(1), nn.Conv2d(c, s, 1), nn.Conv2d(s, c, 1)
+        self.activation, self.scale_activation = nn.SiLU(inplace=True), nn.Sigmoid()
+
+    def forward(self, x):
+        return self.scale_activation(self.fc2(self.activation(self.fc1(self.avgpool(x))))) * x
+
+
+class SD(nn.Module):
+    def __init__(self, p, mode="row"):
+        super().__init__()
+        self.p, self.mode = p, mode
+
+    def forward(self, x):
+        if self.training and self.p > 0.0:
+            raise NotImplementedError("oracle: StochasticDepth in train mode is not restated (inference oracle)")
+        return x
+
+
+class FusedMBConvRef(nn.Module):
+    def __init__(self, expand, k, stride, cin, cout, sd):
+        super().__init__()
+        self.use_res_connect = stride == 1 and cin == cout
+        e = _make_divisible(cin * expand)
+        self.block = nn.Sequential(*([CNA(cin, e, k, stride), CNA(e, cout, 1, act=False)] if e != cin else [CNA(cin, cout, k, stride)]))
+        self.stochastic_depth, self.out_channels = SD(sd), cout
+
+    def forward(self, x):
+        r = self.block(x)
+        return self.stochastic_depth(r) + x if self.use_res_connect else r
+
+
+class MBConvRef(nn.Module):
+    def __init__(self, expand, k, stride, cin, cout, sd):
+        super().__init__()
+        self.use_res_connect = stride == 1 and cin == cout
+        e = _make_divisible(cin * expand)
+        layers = ([CNA(cin, e, 1)] if e != cin else []) + [CNA(e, e, k, stride, groups=e), SE(e, max(1, cin // 4)), CNA(e, cout, 1, act=False)]
+        self.block = nn.Sequential(*layers)
+        self.stochastic_depth, self.out_channels = SD(sd), cout
+
+    def forward(self, x):
+        r = self.block(x)
+        return self.stochastic_depth(r) + x if self.use_res_connect else r
+
+
+class EfficientNetRef(nn.Module):
+    def __init__(self, name, **_ignored):
+        super().__init__()
+        conf, last, dropout = _CONFIGS[name]
+        layers = [CNA(3, conf[0][4], 3, 2)]
+        total, bid = float(sum(c[6] for c in conf)), 0
+        for kind, expand, k, stride, cin, cout, n in conf:
+            stage = []
+            for i in range(n):
+                stage.append((FusedMBConvRef if kind == "fused" else MBConvRef)(expand, k, stride if i == 0 else 1, cin if i == 0 else cout, cout, 0.2 * bid / total))
+                bid += 1
+            layers.append(nn.Sequential(*stage))
+        layers.append(CNA(conf[-1][5], last, 1))
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.classifier = nn.Sequential(nn.Dropout(p=dropout, inplace=True), nn.Linear(last, 1000))
+
+
+def add_to_stub(m: types.ModuleType) -> types.ModuleType:
+    """efficientnet_v2_{s,m,l} constructors on a `torchvision.models` stand-in (`pretrained` ignored)."""
+    for name in _CONFIGS:
+        setattr(m, name, (lambda nm: (lambda *a, **k: EfficientNetRef(nm)))(name))
+    return m
+
+
+# ---- functional restatement on a state_dict (the form the GPU tests call at other sizes) ----
+def _cna(x, sd, p, stride=1, groups=1, act=True, pad=None):
+    w = sd[p + ".0.weight"]
+    y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[-1] - 1) // 2 if pad is None else pad, groups=groups)
+    y = F.batch_norm(y, sd[p + ".1.running_mean"], sd[p + ".1.running_var"], sd[p + ".1.weight"], sd[p + ".1.bias"], False, 0.0, BN_EPS)
+    return F.silu(y) if act else y
+
+
+def _block(x, sd, p, kind, expand, stride, cin, cout):
+    e = _make_divisible(cin * expand)
+    if kind == "fused":
+        r = _cna(_cna(x, sd, p + ".block.0", stride), sd, p + ".block.1", act=False) if e != cin else _cna(x, sd, p + ".block.0", stride)
+    else:
+        i = 0
+        h = x
+        if e != cin:
+            h, i = _cna(h, sd, p + ".block.0"), 1
+        h = _cna(h, sd, f"{p}.block.{i}", stride, groups=e)
+        s = F.adaptive_avg_pool2d(h, 1)
+        s = torch.sigmoid(F.conv2d(F.silu(F.conv2d(s, sd[f"{p}.block.{i + 1}.fc1.weight"], sd[f"{p}.block.{i + 1}.fc1.bias"])),
+                                   sd[f"{p}.block.{i + 1}.fc2.weight"], sd[f"{p}.block.{i + 1}.fc2.bias"]))
+        r = _cna(h * s, sd, f"{p}.block.{i + 2}", act=False)
+    return r + x if (stride == 1 and cin == cout) else r
+
+
+def stage(x, sd, name, fi):
+    """features[fi] of backbone `name` applied to x (state_dict keys 'backbone.features.<fi>....')."""
+    kind, expand, k, stride, cin, cout, n = _CONFIGS[name][0][fi - 1]
+    for b in range(n):
+        x = _block(x, sd, f"backbone.features.{fi}.{b}", kind, expand, stride if b == 0 else 1, cin if b == 0 else cout, cout)
+    return x
+
+
+def encode(sd, x, meta, name, multi_scale_meta=True):
+    """(x1, x2, x3, x4) of semanticFCN_opt.py:396-404 (efficientnet branch); the stem conv is the replaced 3x3 / stride-1 one (:239)."""
+    m = meta.shape[1]
+    xs = _cna(torch.cat([x, meta], 1), sd, "backbone.features.0", stride=1, pad=1)
+    x1 = stage(xs, sd, name, 2)
+    if multi_scale_meta:
+        m1, m2, m3 = (F.interpolate(meta, scale_factor=s, mode="nearest") for s in (1 / 2, 1 / 4, 1 / 8))
+        x2 = stage(torch.cat([x1[:, :-m], m1], 1), sd, name, 3)
+        x3 = stage(torch.cat([x2[:, :-m], m2], 1), sd, name, 4)
+        x4 = torch.cat([x3[:, :-m], m3], 1)
+    else:      # :416-422: without the multi-scale meta the generic chain runs layer4 = features[6:] on x3 (channel mismatch for these backbones)
+        raise NotImplementedError("oracle: efficientnet backbones are restated for multi_scale_meta=True (the reference default) only")
+    return x1, x2, x3, x4

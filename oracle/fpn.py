@@ -96,6 +96,8 @@ def torchvision_models_stub():
     m.resnet18 = lambda *a, **k: ResNetRef(LAYERS["resnet18"])
     m.resnet34 = lambda *a, **k: ResNetRef(LAYERS["resnet34"])
     m.resnet50 = lambda *a, **k: ResNetRef(LAYERS["resnet50"], BottleneckRef)
+    from oracle import effnet as _effnet
+    _effnet.add_to_stub(m)          # efficientnet_v2_{s,m,l}
     return m
 
 

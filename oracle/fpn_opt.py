@@ -38,6 +38,10 @@ def _upsample_block(x, sd, p, scale):                 # :24-28, gn_groups = gcd(
 
 def fpn_opt_forward(sd, x, meta, backbone="resnet18", attention=True, multi_scale_meta=True, dropout_scale=None):
     """logits [B,num_classes,H,W] = SemanticNetworkWithFPN(x, meta) of semanticFCN_opt.py:366-455; dropout_scale [B,C,1,1] or None."""
+    if backbone.startswith("efficientnet_v2"):
+        from oracle import effnet
+        x1, x2, x3, x4 = effnet.encode(sd, x, meta, backbone, multi_scale_meta)
+        return _head(sd, x1, x2, x3, x4, attention, dropout_scale, (4, 4, 2))
     layers = LAYERS[backbone]
     m = meta.shape[1]
     h = torch.cat([x, meta], 1)
@@ -52,11 +56,17 @@ def fpn_opt_forward(sd, x, meta, backbone="resnet18", attention=True, multi_scal
         x2 = _stage(x1, sd, "layer2", layers[1], 2)
         x3 = _stage(x2, sd, "layer3", layers[2], 2)
         x4 = _stage(x3, sd, "layer4", layers[3], 2)
+    return _head(sd, x1, x2, x3, x4, attention, dropout_scale, (8, 4, 2))
+
+
+def _head(sd, x1, x2, x3, x4, attention, dropout_scale, scales):
+    """FPN blocks, SpatialAttention, UpsampleBlocks (scale factors per backbone family, semanticFCN_opt.py:270-285), pyramid dropout, decoder."""
     f4, f3, f2, f1 = _cbr(x4, sd, "fpn_block4"), _cbr(x3, sd, "fpn_block3"), _cbr(x2, sd, "fpn_block2"), _cbr(x1, sd, "fpn_block1")
     if attention:
         f4, f3 = _spatial_attention(f4, sd, "attention4"), _spatial_attention(f3, sd, "attention3")
         f2, f1 = _spatial_attention(f2, sd, "attention2"), _spatial_attention(f1, sd, "attention1")
-    u4, u3, u2 = _upsample_block(f4, sd, "upsample_layer_x4", 8), _upsample_block(f3, sd, "upsample_layer_x3", 4), _upsample_block(f2, sd, "upsample_layer_x2", 2)
+    u4, u3, u2 = (_upsample_block(f4, sd, "upsample_layer_x4", scales[0]), _upsample_block(f3, sd, "upsample_layer_x3", scales[1]),
+                  _upsample_block(f2, sd, "upsample_layer_x2", scales[2]))
     y = torch.cat([f1, u2, u3, u4], 1)
     if dropout_scale is not None:
         y = y * dropout_scale.reshape(y.shape[0], y.shape[1], 1, 1)

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
   const size_t plane = (size_t)a.H * a.W;
   // activation as two leaky slopes (1.0 = identity): before BatchNorm/residual, or (has_act & 4) after them
   const int act_kind = a.has_act & 3;
-  const bool act_late = (a.has_act & 4) != 0, act_tanh = act_kind == 2;
+  const bool act_late = (a.has_act & 4) != 0, act_tanh = act_kind == 2, act_silu = act_kind == 3;
   const float slope_pre = (act_kind == 1 && !act_late) ? a.slope : 1.0f;
   const float slope_post = (act_kind == 1 && act_late) ? a.slope : 1.0f;
   const bool want_stats = a.stats != nullptr;      // wave-uniform
@@ -197,6 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         float v = acc[i][b][r] + s_epi[cl];
         v = v > 0.0f ? v : v * slope_pre;
         if (act_tanh) v = tanhf(v);
+        if (act_silu) v = v / (1.0f + expf(-v));      // nn.SiLU (EfficientNetV2 blocks)
         v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
         if (resid) v += resid[o];
         v = v > 0.0f ? v : v * slope_post;

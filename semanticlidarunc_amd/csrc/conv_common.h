@@ -188,7 +188,7 @@ inline int fill_args(const slu_conv_desc* d, ConvArgs& a) {
   a.nchunks = (d->Cin + d->ck - 1) / d->ck;
   a.nmblk = (d->Cout + 31) / 32;
   a.wpack = d->wpack; a.bias = d->bias; a.bn_a = d->bn_a; a.bn_b = d->bn_b; a.resid = d->resid; a.out = d->out; a.stats = d->stats;
-  if (d->has_act < 0 || d->has_act > 5 || d->has_act == 3 || d->has_act == 4) return SLU_EINVAL;   // tanh has no late form
+  if (d->has_act < 0 || d->has_act > 5 || d->has_act == 4) return SLU_EINVAL;   // 0 none, 1 leaky, 2 tanh, 3 SiLU, 5 = leaky after the residual (tanh / SiLU have no late form)
   a.slope = d->slope; a.has_act = d->has_act;
   a.vec = (d->W % 4 == 0);
   a.gen = 0;

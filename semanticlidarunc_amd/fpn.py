@@ -235,7 +235,7 @@ class SemanticNetworkWithFPN(nn.Module):
         return ops.conv2d_fused(srcs, p.wpack, p.cout, p.k, p.dil, p.pad, bias=p.bias, resid=resid, precision=p.precision,
                                 act=act, act_after_resid=late)
 
-    def _conv_s2(self, name, conv: nn.Conv2d, bn, s2d, cin):
+    def _conv_s2(self, name, conv: nn.Conv2d, bn, s2d, cin, act="relu"):
         """3x3 / stride 2 / pad 1 conv of the tensor whose space-to-depth image is `s2d` ([N, 4*cin, H/2, W/2])."""
         def make():
             w, b = self._fold(conv.weight, conv.bias, bn)
@@ -247,7 +247,7 @@ class SemanticNetworkWithFPN(nn.Module):
                     w2[:, 2 * p + q, :, a, bb] = w[:, :, i, j]
             return w2.reshape(cout, 4 * cin, 2, 2), b, 2, 1, 1
         p = self._prep(name, make, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-        return ops.conv2d_fused([ConvSource(s2d)], p.wpack, p.cout, 2, 1, 1, bias=p.bias, precision=p.precision, act="relu")
+        return ops.conv2d_fused([ConvSource(s2d)], p.wpack, p.cout, 2, 1, 1, bias=p.bias, precision=p.precision, act=act)
 
     def _convT_eq_stride(self, name, ct: nn.ConvTranspose2d, x, out=None, c_off=0):
         s = ct.stride[0]

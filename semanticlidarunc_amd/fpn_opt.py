@@ -21,6 +21,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from . import effnet as _eff
 from . import ops
 from .fpn import SemanticNetworkWithFPN as _FPNBase
 from .fpn import _RESNETS
@@ -54,11 +55,12 @@ class SemanticNetworkWithFPN(_FPNBase):
     def __init__(self, backbone="resnet18", input_channels=2, meta_channel_dim=3, interpolation_mode="nearest", num_classes=3,
                  attention=True, multi_scale_meta=True):
         nn.Module.__init__(self)
-        if backbone not in _RESNETS:
+        self.is_effnet = backbone in _eff.BASE_CHANNELS
+        if backbone not in _RESNETS and not self.is_effnet:
             known = ("regnet_y_400mf", "regnet_y_800mf", "regnet_y_1_6gf", "regnet_y_3_2gf", "shufflenet_v2_x0_5", "shufflenet_v2_x1_0",
-                     "shufflenet_v2_x1_5", "shufflenet_v2_x2_0", "squeezenet1_0", "efficientnet_v2_s", "efficientnet_v2_m", "efficientnet_v2_l")
+                     "shufflenet_v2_x1_5", "shufflenet_v2_x2_0", "squeezenet1_0")
             if backbone in known:
-                raise NotImplementedError(f"backbone '{backbone}' is not implemented on the HIP path yet (resnet18 / resnet34 / resnet50 are)")
+                raise NotImplementedError(f"backbone '{backbone}' is not implemented on the HIP path yet (resnet18 / 34 / 50 and efficientnet_v2_s / m / l are)")
             raise ValueError("Invalid ResNet type. Supported types: 'resnet18', 'resnet34', 'resnet50', 'regnet_y_400mf','regnet_y_800mf', "
                              "'regnet_y_1_6gf', 'regnet_y_3_2gf', 'shufflenet_v2_x0_5', 'shufflenet_v2_x1_0', 'shufflenet_v2_x1_5', "
                              "'shufflenet_v2_x2_0.")
@@ -66,21 +68,104 @@ class SemanticNetworkWithFPN(_FPNBase):
             raise NotImplementedError("only interpolation_mode='nearest' (the reference default) runs on the HIP path")
         self.backbone_name, self.interpolation_mode = backbone, interpolation_mode
         self.num_classes, self.attention, self.multi_scale_meta = num_classes, attention, multi_scale_meta
-        bc = self._build_encoder(backbone, input_channels, meta_channel_dim)
+        bc = self._build_effnet(backbone, input_channels, meta_channel_dim) if self.is_effnet else self._build_encoder(backbone, input_channels, meta_channel_dim)
         self.attention4, self.attention3 = SpatialAttention(bc[1]), SpatialAttention(bc[2])
         self.attention2, self.attention1 = SpatialAttention(bc[3]), SpatialAttention(bc[4])
         self.fpn_block4, self.fpn_block3 = self._fpn(bc[0], bc[1]), self._fpn(bc[1], bc[2])
         self.fpn_block2, self.fpn_block1 = self._fpn(bc[2], bc[3]), self._fpn(bc[3], bc[4])
         self.dropout_pyramid = nn.Dropout2d(p=0.1)
-        out_chs = [bc[1] // 8, bc[2] // 4, bc[3] // 2]
-        self.upsample_layer_x4 = UpsampleBlock(bc[1], out_chs[0], scale=8, mode="bilinear")
-        self.upsample_layer_x3 = UpsampleBlock(bc[2], out_chs[1], scale=4, mode="bilinear")
-        self.upsample_layer_x2 = UpsampleBlock(bc[3], out_chs[2], scale=2, mode="bilinear")
+        # semanticFCN_opt.py:270-285: the efficientnet branch sets is_shuffle (x4 and x3 both sit at 1/8 resolution there)
+        scales, out_chs = ([4, 4, 2], [bc[1] // 4, bc[2] // 4, bc[3] // 2]) if self.is_effnet else ([8, 4, 2], [bc[1] // 8, bc[2] // 4, bc[3] // 2])
+        self.upsample_layer_x4 = UpsampleBlock(bc[1], out_chs[0], scale=scales[0], mode="bilinear")
+        self.upsample_layer_x3 = UpsampleBlock(bc[2], out_chs[1], scale=scales[1], mode="bilinear")
+        self.upsample_layer_x2 = UpsampleBlock(bc[3], out_chs[2], scale=scales[2], mode="bilinear")
         self.decoder_semantic = nn.Sequential(
             nn.Conv2d(sum(out_chs) + bc[4], bc[4], 3, padding=1, bias=False), GN(bc[4]), nn.ReLU(inplace=True),
             nn.Conv2d(bc[4], bc[4], 3, padding=1, bias=False), GN(bc[4]), nn.ReLU(inplace=True),
             UpsampleBlock(bc[4], bc[4] // 2, scale=2),
             nn.Conv2d(bc[4] // 2, num_classes, kernel_size=1))
+
+    # ---------------- EfficientNetV2 encoder (semanticFCN_opt.py:170-180,238-247,396-404) ----------------
+    def _build_effnet(self, backbone, input_channels, meta_channel_dim):
+        """torchvision-shaped efficientnet_v2_{s,m,l} with the reference's surgery: features[0][0] replaced by a 3x3 / stride-1 conv over
+        input + meta channels; stem = features[0], layer1..3 = features[2..4], layer4 = features[6:] (built, never called by forward)."""
+        self.meta_channel_dim = meta_channel_dim
+        self.backbone = _eff.EfficientNetContainer(backbone)
+        f = self.backbone.features
+        f[0][0] = nn.Conv2d(input_channels + meta_channel_dim, f[0][0].out_channels, kernel_size=3, stride=1, padding=1, bias=False)
+        self.stem, self.layer1, self.layer2, self.layer3, self.layer4 = f[0], f[2], f[3], f[4], f[6:]
+        return list(_eff.BASE_CHANNELS[backbone])
+
+    def _cna(self, name, cna, srcs, resid=None, tail_first=0):
+        """Conv2dNormActivation with a dense stride-1 conv: conv -> folded BatchNorm -> SiLU (or none) [+ resid] as one launch."""
+        return self._conv(name, cna[0], cna[1], srcs, act="silu" if len(cna) > 2 else "none", resid=resid, tail_first=tail_first)
+
+    def _cna_s2(self, name, cna, s2d, cin):
+        """... with the 3x3 / stride-2 conv of a stage's first FusedMBConv: 2x2 stride-1 conv on the space-to-depth image."""
+        return self._conv_s2(name, cna[0], cna[1], s2d, cin, act="silu" if len(cna) > 2 else "none")
+
+    def _dw(self, name, cna):
+        """(w [C, 9], bias [C]) of a depthwise Conv2dNormActivation with the eval BatchNorm folded in (cached per parameter version)."""
+        conv, bn = cna[0], cna[1]
+
+        def make():
+            w, b = self._fold(conv.weight, None, bn)
+            return w, b, 3, 1, 1
+        cache = self.__dict__.setdefault("_dw_cache", {})
+        key = tuple((t.data_ptr(), t._version) for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            w, b, *_ = make()
+            hit = cache[name] = (key, w.detach().float().reshape(w.shape[0], 9).contiguous(), b.detach().float().contiguous())
+        return hit[1], hit[2]
+
+    def _eff_block(self, name, blk, x, meta_k=None):
+        """One FusedMBConv / MBConv block, eval mode (StochasticDepth = identity).  meta_k: the meta channels that replace the last m input
+        channels (first block of a stage, semanticFCN_opt.py:399-403)."""
+        seq = blk.block
+        cx = x.shape[1]
+        m = 0 if meta_k is None else meta_k.shape[1]
+        resid = x if blk.use_res_connect else None
+        if isinstance(blk, _eff.FusedMBConv):
+            first = seq[0]
+            if first[0].stride[0] == 2:
+                s2d = ops.space_to_depth2(x) if meta_k is None else ops.space_to_depth2_cat(x, cx - m, meta_k)
+                h = self._cna_s2(name + ".0", first, s2d, cx)
+            else:
+                src = [ConvSource(x)] if meta_k is None else [ConvSource(meta_k), ConvSource(x, None, False, 0, cx - m)]
+                h = self._cna(name + ".0", first, src, resid=resid if len(seq) == 1 else None, tail_first=m)
+            return h if len(seq) == 1 else self._cna(name + ".1", seq[1], [ConvSource(h)], resid=resid)
+        i = 0
+        h = x
+        src = [ConvSource(x)] if meta_k is None else [ConvSource(meta_k), ConvSource(x, None, False, 0, cx - m)]
+        if len(seq) == 4:                                               # 1x1 expansion
+            h, i = self._cna(name + ".0", seq[0], src, tail_first=m), 1
+        elif meta_k is not None:
+            raise NotImplementedError("meta injection into an MBConv without expansion does not occur in the V2 configurations")
+        dw, se, proj = seq[i], seq[i + 1], seq[i + 2]
+        w9, b9 = self._dw(f"{name}.{i}", dw)
+        h = ops.dwconv3x3(h, w9, b9, dw[0].stride[0], "silu")
+        c, s = se.fc1.in_channels, se.fc1.out_channels
+        scale = ops.se_scale(h, se.fc1.weight.detach().reshape(s, c).contiguous(), se.fc1.bias.detach(), se.fc2.weight.detach().reshape(c, s).contiguous(),
+                             se.fc2.bias.detach())
+        return self._cna(f"{name}.{i + 2}", proj, [ConvSource(h, scale)], resid=resid)      # SE multiplies the projection's input per (sample, channel)
+
+    def _eff_stage(self, lname, stage, x, meta_k):
+        for bi, blk in enumerate(stage):
+            x = self._eff_block(f"{lname}.{bi}", blk, x, meta_k if bi == 0 else None)
+        return x
+
+    def _encode_effnet(self, x, meta):
+        if not self.multi_scale_meta:
+            raise NotImplementedError("efficientnet backbones run with multi_scale_meta=True only (the reference's other branch feeds layer4 = "
+                                      "features[6:] a tensor of the wrong channel count)")
+        m1, m2, m3 = ops.nearest_down(meta, 2), ops.nearest_down(meta, 4), ops.nearest_down(meta, 8)
+        xs = self._cna("stem", self.stem, [ConvSource(x), ConvSource(meta)])
+        x1 = self._eff_stage("layer1", self.layer1, xs, None)
+        x2 = self._eff_stage("layer2", self.layer2, x1, m1)
+        x3 = self._eff_stage("layer3", self.layer3, x2, m2)
+        x4 = ops.replace_tail(x3, m3)                                     # :404: x4 = cat(x3[:, :-m], meta3) -- layer4 is never applied
+        return x1, x2, x3, x4
 
     # ---------------- head pieces ----------------
     def _spatial_attention(self, name, att: SpatialAttention, x):
@@ -162,9 +247,14 @@ class SemanticNetworkWithFPN(_FPNBase):
 
     def _forward(self, x, meta_channel, drop_scale):
         x, meta = self._check_inputs(x, meta_channel)
-        if self._wants_autograd(x, meta):
+        if self.is_effnet:
+            if any(isinstance(mod, nn.modules.batchnorm._BatchNorm) and mod.training for mod in self.modules()):
+                raise NotImplementedError("the EfficientNetV2 encoder runs in eval mode only on the HIP path (no training path yet); call .eval()")
+            x1, x2, x3, x4 = self._encode_effnet(x, meta)
+        elif self._wants_autograd(x, meta):
             return self._forward_train_opt(x, meta, drop_scale)
-        x1, x2, x3, x4 = self._encode(x, meta)
+        else:
+            x1, x2, x3, x4 = self._encode(x, meta)
         f4 = self._conv("fpn4", self.fpn_block4[0], self.fpn_block4[1], [ConvSource(x4)])
         f3 = self._conv("fpn3", self.fpn_block3[0], self.fpn_block3[1], [ConvSource(x3)])
         f2 = self._conv("fpn2", self.fpn_block2[0], self.fpn_block2[1], [ConvSource(x2)])

@@ -233,9 +233,11 @@ def conv2d_fused(srcs: Sequence[ConvSource], wpack: torch.Tensor, cout: int, ksi
     d.wpack, d.bias = wpack.data_ptr(), _ptr(bias)
     d.has_act, d.slope = (0, 0.0) if slope is None else (1, float(slope))
     if act is not None:                     # explicit activation kind overrides `slope`
-        if act not in ("relu", "tanh", "none"):
+        if act not in ("relu", "tanh", "silu", "none"):
             raise ValueError(f"unknown activation {act!r}")
-        d.has_act, d.slope = {"relu": (1, 0.0), "tanh": (2, 0.0), "none": (0, 0.0)}[act]
+        d.has_act, d.slope = {"relu": (1, 0.0), "tanh": (2, 0.0), "silu": (3, 0.0), "none": (0, 0.0)}[act]
+        if act_after_resid and act in ("tanh", "silu"):
+            raise ValueError(f"activation {act!r} has no after-the-residual form")
     if act_after_resid and d.has_act:
         d.has_act |= 4
     d.bn_a, d.bn_b, d.resid, d.out = _ptr(bn_a), _ptr(bn_b), _ptr(resid), out.data_ptr()
@@ -1317,3 +1319,39 @@ class DropoutPlan:
         check(_lib.load().slu_dropout_draw(self.sites.data_ptr(), self.nsites, self.outs.data_ptr(), self.nout, self.n, seed & (2 ** 64 - 1), off, buf.data_ptr(),
                                            self.total, _stream()), "slu_dropout_draw")
         return {key: buf[b:b + self.n * c].view(self.n, c) for key, b, c in self.slices}
+
+
+# ------------------------------------------------------------------------------------------------
+# EfficientNetV2 pieces (csrc/effnet_ops.hip)
+# ------------------------------------------------------------------------------------------------
+def dwconv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, act: str = "none") -> torch.Tensor:
+    """Depthwise 3x3 (padding 1, stride 1 / 2) + bias [+ SiLU]; w [C, 9] (eval BatchNorm already folded in)."""
+    _req(x, "x")
+    _req(w, "w")
+    n, c, h, wd = x.shape
+    if tuple(w.shape) != (c, 9) or (bias is not None and bias.numel() != c):
+        raise RuntimeError(f"dwconv3x3: weight {tuple(w.shape)} / bias do not match {c} channels")
+    if bias is not None:
+        _req(bias, "bias")
+    oh, ow = (h + stride - 1) // stride, (wd + stride - 1) // stride
+    y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_dwconv3x3_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, c, h, wd, int(stride), {"none": 0, "silu": 3}[act],
+                                        _stream()), "slu_dwconv3x3_fwd")
+    return y
+
+
+def se_scale(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, b2: Optional[torch.Tensor]) -> torch.Tensor:
+    """SqueezeExcitation's multiplier [N, C] = sigmoid(fc2(SiLU(fc1(mean_HW(x))))); w1 [S, C], w2 [C, S]."""
+    _req(x, "x")
+    n, c, h, w = x.shape
+    s = w1.shape[0]
+    for t, nme, shp in ((w1, "w1", (s, c)), (w2, "w2", (c, s))):
+        _req(t, nme)
+        if tuple(t.shape) != shp:
+            raise RuntimeError(f"se_scale: {nme} expected {shp}, got {tuple(t.shape)}")
+    lib = _lib.load()
+    avg = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    check(lib.slu_global_avgpool(x.data_ptr(), avg.data_ptr(), n, c, h * w, _stream()), "slu_global_avgpool")
+    scale = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    check(lib.slu_se_gate(avg.data_ptr(), w1.data_ptr(), _ptr(b1), w2.data_ptr(), _ptr(b2), scale.data_ptr(), n, c, s, _stream()), "slu_se_gate")
+    return scale

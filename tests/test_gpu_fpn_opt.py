@@ -96,6 +96,6 @@ def test_contract_errors(cuda):
     with pytest.raises(ValueError):
         SemanticNetworkWithFPN("vgg")
     with pytest.raises(NotImplementedError):
-        SemanticNetworkWithFPN("efficientnet_v2_l")
+        SemanticNetworkWithFPN("regnet_y_400mf")
     with pytest.raises(RuntimeError):
         m.eval()(torch.zeros(1, 2, 16, 64), torch.zeros(1, 3, 16, 64))            # CPU tensors

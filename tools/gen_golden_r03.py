@@ -2,7 +2,7 @@
 """Round-3 additions to the pinned fixtures: same rules as tools/gen_golden.py (runs ONLY in the build container, imports the reference
 read-only from /root/reference, writes small data-only fixtures under tests/golden/).
 
-    python tools/gen_golden_r03.py [fpn_train] [fpn_opt_train]
+    python tools/gen_golden_r03.py [fpn_train] [fpn_opt_train] [effnet]
 
 fpn_train / fpn_opt_train: one TRAINING step of the reference's own classes (models/semanticFCN.py, baselines/Reichert/semanticFCN_opt.py) in
 train mode -- batch-statistics BatchNorm, running-statistics update, loss = sum(out * R), backward -- through the stub torchvision.models that
@@ -178,7 +178,55 @@ def gen_fpn_opt_train():
     np.save(os.path.join(OUT, "fpn_opt_train_resnet18_dropout_scale.npy"), scale.numpy())
 
 
+def gen_effnet():
+    """f-4, second half: semanticFCN_opt with the EfficientNetV2 backbones (the shipped YAML's `model_type: efficientnet_v2_l`,
+    configs/SemanticKitti_default.yaml:14), eval mode: the reference's own class through the stub torchvision.models serving oracle/effnet.py's
+    restated blocks.  Pins which stages the model uses, the meta injection, x4 = cat(x3[:, :-m], meta3), the [4, 4, 2] up-sampling ladder, the head
+    and the state_dict layout; the block internals rest on the public torchvision definition (its published parameter counts are asserted)."""
+    import json
+    _stub_torchvision()
+    from baselines.Reichert.semanticFCN_opt import SemanticNetworkWithFPN as RefOpt
+    from oracle import effnet as oeff, fpn_opt as ofpo
+    from semanticlidarunc_amd.fpn_opt import SemanticNetworkWithFPN as MyOpt
+    from semanticlidarunc_amd.testing import randomize_bn_
+    published = {"efficientnet_v2_s": 21458488, "efficientnet_v2_m": 54139356, "efficientnet_v2_l": 118515272}      # torchvision docs: num_params
+    for name, n in published.items():
+        got = sum(p.numel() for p in oeff.EfficientNetRef(name).parameters())
+        assert got == n, (name, got, n)
+    print("  restated efficientnet_v2_{s,m,l}: parameter counts equal torchvision's published ones")
+    for tag, kw, shape in (("efficientnet_v2_l_m3_c20", dict(backbone="efficientnet_v2_l", input_channels=2, meta_channel_dim=3, num_classes=20), (1, 32, 128)),
+                           ("efficientnet_v2_s_m6_c5_noatt", dict(backbone="efficientnet_v2_s", input_channels=2, meta_channel_dim=6, num_classes=5,
+                                                                   attention=False), (2, 32, 64))):
+        torch.manual_seed(0)
+        mine = randomize_bn_(MyOpt(**kw), 3).eval()
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(9)
+            for mod in mine.modules():
+                if isinstance(mod, torch.nn.GroupNorm):
+                    mod.weight.copy_(torch.rand(mod.num_channels, generator=g) + 0.5)
+                    mod.bias.copy_(torch.randn(mod.num_channels, generator=g) * 0.1)
+        ref = RefOpt(**kw)
+        sdf = mine.state_dict()
+        assert list(sdf.keys()) == list(ref.state_dict().keys()), "state_dict key order differs from the reference class"
+        assert all(tuple(a.shape) == tuple(b.shape) for a, b in zip(sdf.values(), ref.state_dict().values()))
+        ref.load_state_dict(sdf)
+        ref.eval()
+        g = torch.Generator().manual_seed(51)
+        xf = torch.randn(shape[0], 2, shape[1], shape[2], generator=g) * torch.tensor([20.0, 0.3]).view(1, 2, 1, 1)
+        mf = torch.randn(shape[0], kw["meta_channel_dim"], shape[1], shape[2], generator=g) * 5.0
+        with torch.no_grad():
+            yr = ref(xf, mf)
+            yo = ofpo.fpn_opt_forward(sdf, xf, mf, kw["backbone"], kw.get("attention", True), True)
+        print(f"FPN-opt {tag}: |oracle - reference| = {float((yr - yo).abs().max()):.3e}  (|logit| max {float(yr.abs().max()):.2f}, {len(sdf)} state_dict entries)")
+        assert float((yr - yo).abs().max()) <= 1e-5 * max(1.0, float(yr.abs().max()))
+        s_ = sum(float(v.double().sum()) for v in sdf.values() if v.is_floating_point())
+        a_ = sum(float(v.double().abs().sum()) for v in sdf.values() if v.is_floating_point())
+        save("fpn_opt_" + tag, x=xf.numpy(), meta=mf.numpy(), out=yr.numpy(), sd_digest=np.array([s_, a_]))
+    with open(os.path.join(OUT, "fpn_opt_efficientnet_v2_s_state_dict_keys.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in RefOpt("efficientnet_v2_s", 2, 3, num_classes=20).state_dict().items()}, f, indent=0)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["fpn_train"]
     for w in what:
-        {"fpn_train": gen_fpn_train, "fpn_opt_train": gen_fpn_opt_train}[w]()
+        {"fpn_train": gen_fpn_train, "fpn_opt_train": gen_fpn_opt_train, "effnet": gen_effnet}[w]()
