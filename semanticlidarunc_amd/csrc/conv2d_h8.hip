@@ -56,6 +56,7 @@ struct H8Args {
   int out_f32;         // 1: `out` is fp32 NCHW [N][Cout][H][W] (the logits head); 0: h8
   int tiles_x, tiles_y;
   int order;                 // 0: each workgroup walks a contiguous run of tiles; 1: tiles interleaved across workgroups
+  int dbg;                   // development switches of gemm1x1_h8_kernel (SLU_GEMM_DBG): 1 no input DMA, 2 no weight DMA, 4 no MFMA
 };
 
 struct SrcSel {
@@ -887,6 +888,161 @@ __global__ __launch_bounds__(256, (MB * NKS >= 12) ? 2 : ((MB * NKS >= 2) ? 3 : 
   }
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// Wide 1x1 convs with 256 output channels (768 -> 256 concat convs and the 128 / 256 -> 256 shortcuts of the U-Net's lower levels) as a plain
+// GEMM, out[Cout][pixels] = W[Cout][Cin] x[Cin][pixels]: BOTH operands go global -> LDS by global_load_lds into a ring of D chunks of KC K-steps,
+// D - 1 in flight, issued as one burst behind the barrier that frees the slot; one barrier per chunk; every wave issues the same number of DMAs
+// at every position (beyond the end: the zero record), so "chunk c has landed" is the constant vmcnt((D - 2) NPIECE).  A workgroup of 8 waves
+// (2 along the channels x 4 along the pixels) owns 256 consecutive pixels of one image plane and all channels: the weights stream once per 256
+// pixels (the streaming conv1x1_h8_kernel re-reads them per 128 and stages them through registers + two barriers per 64 channels).
+// Measured (N = 64, tools/h8_1x1_bench.py): 768 -> 256 at 16x512 504 -> 459 us, 128 -> 256 at 16x512 117 -> 96, 256 -> 256 at 8x256 46 -> 38; the
+// 128-output instantiation is 17 % SLOWER than the streaming kernel (544 -> 634 us at 32x1024) and is not dispatched.  What the ablation
+// switches (H8Args.dbg / SLU_GEMM_DBG) showed on 768 -> 256: no input DMA 399 us, no weight DMA 413, no MFMA 354, none of the three STILL 306 of
+// 481 -- the time is in the per-chunk skeleton (32 DMA instructions per CU and chunk, barrier, fragment reads) and the epilogue, not in HBM,
+// L2 or the matrix cores; a deeper ring of smaller chunks (KC 2, D 4) was slower (484) than two 64-channel chunks (459).
+// With a residual the epilogue's loads drain the ring once per tile (the compiler's vmcnt(0)); without, the stores stay in flight.
+// Needs: Cout = 64 MB, H W % 256 == 0, nks % KC == 0, every source a whole number of chunks, no multipliers / batch broadcast.
+// -----------------------------------------------------------------------------------------------------------
+template <int MB, int KC, int D>
+__global__ __launch_bounds__(512, 2) void gemm1x1_h8_kernel(const H8Args a, const void* __restrict__ resid, void* __restrict__ out) {
+  constexpr int NWAVE = 8, MBLK = 2 * MB, TP = 256, NB = 2;
+  constexpr int NREC_A = MBLK * KC * 64, NREC_B = 2 * KC * TP;           // records per chunk: weight fragments, input tile [2 KC blocks][256 px]
+  constexpr int NPA = MBLK * KC, NPB = 2 * KC * 4;                       // 64-record pieces
+  constexpr int NIA = (NPA + NWAVE - 1) / NWAVE, NIB = NPB / NWAVE;
+  constexpr int NPIECE = NIA + NIB;
+  static_assert(NPB % NWAVE == 0 && NPA % NWAVE == 0 && D >= 2 && (D - 2) * NPIECE <= 63, "pieces divide over the waves; vmcnt is 6 bits");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_epi = reinterpret_cast<float*>(smem);                         // bias | bn_a | bn_b
+  uint4* s_b = reinterpret_cast<uint4*>(s_epi + 3 * MBLK * 32);          // [D][NREC_B]
+  uint4* s_a = s_b + D * NREC_B;                                         // [D][MBLK][KC][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, hh = lane >> 5, jj = lane & 31;
+  const size_t HW = (size_t)a.H * a.W;
+  const int tiles_per_img = (int)(HW / TP);
+  const int ntiles = tiles_per_img * a.N, nch = a.nks / KC;
+  const int t_step = gridDim.x, t_beg = (int)blockIdx.x;
+  if (t_beg >= ntiles) return;
+
+  if (tid < MBLK * 32) {
+    const bool ok = tid < a.Cout;
+    s_epi[tid] = (ok && a.bias) ? a.bias[tid] : 0.0f;
+    s_epi[MBLK * 32 + tid] = (ok && a.bn_a) ? a.bn_a[tid] : 1.0f;
+    s_epi[2 * MBLK * 32 + tid] = (ok && a.bn_a) ? a.bn_b[tid] : 0.0f;
+  }
+  uintptr_t zero_addr = reinterpret_cast<uintptr_t>(&g_zero_rec), trash_addr = reinterpret_cast<uintptr_t>(&g_trash_rec);
+  asm volatile("" : "+s"(zero_addr));
+  asm volatile("" : "+s"(trash_addr));
+
+  // the staging cursor runs D - 1 chunks ahead of the compute cursor: (s_tile, s_q) = the next chunk to copy, into ring slot s_slot
+  int s_tile = t_beg, s_q = 0, s_slot = 0;
+  auto stage_next = [&]() __attribute__((always_inline)) {
+    const bool valid = s_tile < ntiles;
+    int wv = wave;
+    asm volatile("" : "+s"(wv));                                        // (keeps the per-piece address arithmetic out of the loop-invariant set)
+    uintptr_t base = zero_addr;
+    if (valid) {
+      const int n = s_tile / tiles_per_img, p0 = (s_tile - n * tiles_per_img) * TP;
+      const int g = 2 * KC * s_q;                                        // first channel block of the chunk: one source holds the whole chunk
+      const uint4* ptr = a.src[0].ptr;
+      int G = a.src[0].G, gl = g;
+#pragma unroll
+      for (int s = 1; s < SLU_MAX_SRC; ++s)
+        if (s < a.nsrc && g >= a.src[s].gbeg) ptr = a.src[s].ptr, G = a.src[s].G, gl = g - a.src[s].gbeg;
+      base = reinterpret_cast<uintptr_t>(ptr) + 16 * (((size_t)n * G + gl) * HW + p0);
+    }
+    uint4* db = s_b + s_slot * NREC_B;
+    uint4* da = s_a + s_slot * NREC_A;
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int p = i * NWAVE + wv;                                      // block = p / 4, pixel quarter = p % 4
+      const uintptr_t src = (valid && !(a.dbg & 1)) ? base + 16 * ((size_t)(p >> 2) * HW + (size_t)((p & 3) * 64 + lane)) : zero_addr;
+      SLU_GLDS16(reinterpret_cast<const uint4*>(src), db + p * 64);
+    }
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int p = i * NWAVE + wv;                                      // = m * KC + ks
+      const int m = p / KC, ks = p - m * KC;
+      const uint4* src = (valid && !(a.dbg & 2)) ? a.wpack + ((size_t)m * a.nks + KC * s_q + ks) * 64 + lane : reinterpret_cast<const uint4*>(zero_addr);
+      SLU_GLDS16(src, da + p * 64);
+    }
+    asm volatile("" ::: "memory");
+    s_slot = s_slot + 1 == D ? 0 : s_slot + 1;
+    if (++s_q == nch) s_q = 0, s_tile += t_step;
+  };
+#pragma unroll
+  for (int c = 0; c < D - 1; ++c) stage_next();
+
+  int r_slot = 0;
+  const float slope_pre = (a.has_act & 3) == 1 ? a.slope : 1.0f;
+  const uint2* resid2 = reinterpret_cast<const uint2*>(resid);
+  const int abase = (wm * MB) * KC * 64 + lane;
+  const int bbase = hh * TP + wn * 64 + jj;
+
+  for (int tile = t_beg; tile < ntiles; tile += t_step) {
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
+    for (int q = 0; q < nch; ++q) {
+      // the oldest chunk in flight has landed once at most the (D - 2) younger chunks' pieces are outstanding (stores of an epilogue in
+      // between only make the wait stricter); then every wave is past its reads of the slot that is re-filled next
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NPIECE) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stage_next();
+      const uint4* sb = s_b + r_slot * NREC_B + bbase;
+      const uint4* sa = s_a + r_slot * NREC_A + abase;
+      r_slot = r_slot + 1 == D ? 0 : r_slot + 1;
+      half8 af[2][MB], bf[2][NB];
+      auto read_frags = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) af[set][i] = __builtin_bit_cast(half8, sa[(i * KC + ks) * 64]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bf[set][b] = __builtin_bit_cast(half8, sb[2 * ks * TP + b * 32]);
+      };
+      read_frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < KC; ++ks) {
+        if (ks + 1 < KC) read_frags((ks + 1) & 1, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(a.dbg & 4)) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][b], acc[i][b], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < MB; ++i) asm volatile("" ::"v"(af[ks & 1][i]));
+#pragma unroll
+          for (int b = 0; b < NB; ++b) asm volatile("" ::"v"(bf[ks & 1][b]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {
+      const int n = tile / tiles_per_img, p0 = (tile - n * tiles_per_img) * TP;
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int ml = wm * MB + i;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const size_t pix = (size_t)p0 + wn * 64 + b * 32 + jj;
+          store_tile_swap16<MBLK * 32>(a, acc[i][b], s_epi, ml * 32, ml * 4, hh, true, (size_t)n, pix, HW, resid2, reinterpret_cast<uint4*>(out), slope_pre,
+                                       zero_addr, trash_addr);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // zero-record DMAs issued beyond the last chunk: LDS must not be released under them
+}
+
 // wpack[mblk][kstep][tap][lane][8]: lane (r, h) holds W[co = 32 mblk + r][ci = 16 kstep + 8 h + j][tap], j = 0..7, as fp16
 __global__ void pack_h8_kernel(const float* __restrict__ w, int cout, int cin, int ks, int nks, size_t total, uint4* __restrict__ out) {
   const int T = ks * ks;
@@ -1063,6 +1219,7 @@ int fill_h8(const slu_conv_h8_desc* d, H8Args& a) {
   a.has_act = d->has_act; a.slope = d->slope;
   a.out_f32 = d->out_f32_nchw ? 1 : 0;
   a.tiles_x = a.tiles_y = 0;
+  a.dbg = [] { const char* e = getenv("SLU_GEMM_DBG"); return e ? atoi(e) : 0; }();
   return SLU_OK;
 }
 
@@ -1505,6 +1662,35 @@ const char* res_1x1_name(const H8Args& a, char* buf, size_t n) {
   return buf;
 }
 
+// the layers gemm1x1_h8_kernel covers; SLU_H8_GEMM1X1=0 is the A/B switch back to the streaming kernels
+constexpr int GEMM1X1_KC = 4, GEMM1X1_D256 = 2, GEMM1X1_D128 = 3;      // chunk = 64 channels; ring: 2 x 64 KB (256 outputs), 3 x 48 KB (128)
+bool gemm1x1_ok(const slu_conv_h8_desc* d, const H8Args& a) {
+  static const bool off = [] { const char* e = getenv("SLU_H8_GEMM1X1"); return e && e[0] == '0'; }();
+  // 256 output channels only: measured (tools/h8_1x1_bench.py, N = 64) 5 ... 18 % faster than the streaming kernel there (768->256 at 16x512:
+  // 504 -> 459 us) and 17 % SLOWER for 128 outputs (384->128 at 32x1024: 544 -> 634 us), whose instantiation stays available to the tests
+  static const bool all = [] { const char* e = getenv("SLU_H8_GEMM1X1"); return e && e[0] == '2'; }();
+  if (off || d->ksize != 1 || d->pad != 0 || a.out_f32 || (a.Cout != 256 && !(all && a.Cout == 128))) return false;
+  if (((long long)a.H * a.W) % 256 || a.nks % GEMM1X1_KC || a.Gin != 2 * a.nks) return false;
+  if ((a.has_act & ~1) || ((a.has_act & 1) && !(a.slope >= 0.0f && a.slope <= 1.0f))) return false;
+  for (int s = 0; s < a.nsrc; ++s)
+    if (a.src[s].scale || a.src[s].nb || a.src[s].G % (2 * GEMM1X1_KC)) return false;
+  return (long long)a.N * a.H * a.W / 256 <= 0x7fffffffLL;
+}
+
+template <int MB, int D>
+int launch_gemm1x1(H8Args& a, const slu_conv_h8_desc* d, hipStream_t st) {
+  constexpr int KC = GEMM1X1_KC, MBLK = 2 * MB;
+  constexpr size_t lds = (size_t)3 * MBLK * 32 * 4 + (size_t)D * (2 * KC * 256) * 16 + (size_t)D * (MBLK * KC * 64) * 16;
+  static_assert(lds <= 160 * 1024, "gemm1x1 LDS");
+  const long long nt = (long long)a.N * a.H * a.W / 256;
+  const long long gx = nt < 256 ? nt : 256;
+  auto kern = gemm1x1_h8_kernel<MB, KC, D>;
+  static SluLdsGrant grant;
+  if (slu_grant_dynamic_lds(reinterpret_cast<const void*>(kern), lds, grant) != SLU_OK) return SLU_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(512), lds, st, a, d->resid, d->out);
+  SLU_CHECK_LAUNCH();
+}
+
 bool any_scale(const slu_conv_h8_desc* d) {
   for (int s = 0; s < d->nsrc; ++s)
     if (d->src[s].scale) return true;
@@ -1538,6 +1724,7 @@ extern "C" int slu_conv2d_h8_fwd(const slu_conv_h8_desc* d, slu_stream_t stream)
   const int rc = fill_h8(d, a);
   if (rc != SLU_OK) return rc;
   hipStream_t st = slu_stream(stream);
+  if (gemm1x1_ok(d, a)) return a.Cout == 128 ? launch_gemm1x1<2, GEMM1X1_D128>(a, d, st) : launch_gemm1x1<4, GEMM1X1_D256>(a, d, st);
   if (stream_ok(d, a)) {
     if (a.nmblk <= 2) {
       const int rc2 = a.nmblk == 1 ? launch_h8_1x1_res_nks<1>(a, d, st) : launch_h8_1x1_res_nks<2>(a, d, st);
@@ -1570,6 +1757,10 @@ extern "C" int slu_conv2d_h8_kernel_name(const slu_conv_h8_desc* d, char* buf, s
   H8Args a{};
   const int rc = fill_h8(d, a);
   if (rc != SLU_OK || !buf || n == 0) return rc != SLU_OK ? rc : SLU_EINVAL;
+  if (gemm1x1_ok(d, a)) {
+    snprintf(buf, n, "gemm1x1_h8_kernel<%d, %d, %d>", a.Cout / 64, GEMM1X1_KC, a.Cout == 128 ? GEMM1X1_D128 : GEMM1X1_D256);
+    return SLU_OK;
+  }
   if (stream_ok(d, a)) {
     if (res_1x1_name(a, buf, n)) return SLU_OK;
     const int mb = a.nmblk == 1 ? 1 : (a.nmblk == 2 ? 2 : (a.nmblk <= 4 ? 4 : 8));

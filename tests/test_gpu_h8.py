@@ -116,6 +116,29 @@ def test_concat_scales_broadcast_and_fp32_head(cuda):
     _conv_case(cuda, 1, [32], 20, 5, 33, (1, 1, 0), seed=17, out_f32=True)                # odd H*W: tiled form of the head
 
 
+@pytest.mark.parametrize("parts,cout,n,hw,resid", [
+    ([128, 128, 128], 128, 3, (16, 64), True),       # ResBlock / UpBlock concat conv of a 128-channel block + shortcut residual
+    ([256, 256, 256], 256, 2, (8, 64), True),        # ... of a 256-channel block: 12 chunks of 64 channels
+    ([256, 256, 256], 256, 5, (4, 128), False),      # H W = 512: two 256-pixel tiles per image, odd image count
+    ([64], 128, 2, (16, 64), False), ([128], 256, 2, (8, 64), False), ([256], 256, 1, (4, 64), True),      # the shortcut 1x1 convs (1 / 2 / 4 chunks)
+    ([64, 192], 256, 2, (8, 32), False)])            # two sources of unequal (whole-chunk) widths
+def test_wide_1x1_gemm_kernel(cuda, parts, cout, n, hw, resid):
+    """gemm1x1_h8_kernel (both operands through the LDS double buffer): multi-chunk layers, several tiles per workgroup, tensors whose last tile
+    ends at the allocation boundary (every tensor here is exactly as large as the kernel's last access)."""
+    _conv_case(cuda, n, parts, cout, hw[0], hw[1], (1, 1, 0), seed=sum(parts) + cout + n, resid=resid)
+
+
+def test_wide_1x1_gemm_kernel_is_the_one_that_runs(cuda):
+    from semanticlidarunc_amd import ops
+    ops.TIMING, ops.TIMING_TAGS = [], []
+    try:
+        _conv_case(cuda, 2, [256, 256, 256], 256, 8, 64, (1, 1, 0), seed=1)
+        names = [t[0] for t in ops.TIMING]
+    finally:
+        ops.TIMING = None
+    assert names == ["gemm1x1_h8_kernel<4, 4, 2>"], names
+
+
 @pytest.mark.parametrize("dil", [1, 2])
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64)])
 def test_deep_ring_3x3_full_resolution_layers(cuda, cin, cout, dil):
