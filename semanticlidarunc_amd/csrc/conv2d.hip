@@ -178,14 +178,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
   const float slope_pre = (act_kind == 1 && !act_late) ? a.slope : 1.0f;
   const float slope_post = (act_kind == 1 && act_late) ? a.slope : 1.0f;
   const bool want_stats = a.stats != nullptr;      // wave-uniform
-#pragma unroll
-  for (int i = 0; i < MB; ++i) {
+  // The accumulator indices must be COMPILE-TIME constants: with a plain `#pragma unroll` over i the body (NB x 16 stores + the statistics
+  // butterfly) was too large for the unroller in the MB = 2, NB = 4 instantiations ("loop not unrolled"), acc[i][b] became a dynamic index and
+  // the whole accumulator array lived in scratch memory -- 360 scratch loads / stores around the 288 MFMAs of the K loop of the largest tiles.
+  slu_static_for<MB>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
     const int ml = wm * MB + i;               // channel block inside the workgroup tile
     float ssum[16], ssq[16];                  // this lane's share of the batch statistics (its NB pixels of 16 channels)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.0f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
+    slu_static_for<NB>([&](auto bc) __attribute__((always_inline)) {
+      constexpr int b = decltype(bc)::value;
       const int gy = y0 + wn * RPW + (b >> 1), gx = x0 + (b & 1) * 32 + jj;
       const bool pix_ok = gy < a.H && gx < a.W;
 #pragma unroll
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         if (ok) out[o] = v;
         if (want_stats && ok) { ssum[r] += v; ssq[r] += v * v; }
       }
-    }
+    });
     if (want_stats) {
       // the 32 lanes of a half hold 32 pixels of the same 16 channels: butterfly over them, lane 0 of each half adds the tile's share
       // to the workgroup's LDS accumulators (float), which go out as one double atomic per channel at the end
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         }
       }
     }
-  }
+  });
   if (want_stats) {
     __syncthreads();
     if (tid < MBLK * 32) {

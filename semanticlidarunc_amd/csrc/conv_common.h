@@ -1,6 +1,7 @@
 // Definitions shared by the conv kernels (fp32-exact and split-fp16): launch arguments, input addressing
 // (concatenated sources, PixelShuffle, folded-dropout multipliers), tile-shape choice.
 #pragma once
+#include <utility>
 #include <stdio.h>
 
 #include "slu_common.h"
@@ -18,6 +19,17 @@ struct SrcDev {
   int ccount;  // number of conv-input channels contributed
   int nb;      // images held by the tensor (output image n reads image n % nb); 0 = N
 };
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}) -- for bodies too large for `#pragma unroll`
+// whose index must stay a constant (register arrays indexed by it would otherwise move to scratch memory)
+template <class F, int... Is>
+__device__ __forceinline__ void slu_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void slu_static_for(F&& f) {
+  slu_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 struct ConvArgs {
   SrcDev src[SLU_MAX_SRC];

@@ -474,7 +474,7 @@ class _ZeroArena:
     CHUNK = 1 << 16
 
     def __init__(self):
-        self._chunks = {}          # device -> [tensor, next free element]
+        self._chunks = {}          # (device, stream) -> [tensor, next free element]
 
     def take(self, shape, device) -> torch.Tensor:
         n = 1
@@ -482,7 +482,11 @@ class _ZeroArena:
             n *= int(d)
         if n > self.CHUNK // 4 or torch.cuda.is_current_stream_capturing():
             return torch.zeros(shape, dtype=torch.float64, device=device)
-        key = torch.device(device)
+        # one chunk per (device, stream): the fill is ordered before the consumers only on the stream it was issued on, and the caching
+        # allocator may hand a dropped chunk's block out again on that stream while another stream's kernels still add into it (the dropout
+        # side stream and the graph warm-up stream of this package are real second streams)
+        dev = torch.device(device)
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
         ent = self._chunks.get(key)
         if ent is None or ent[1] + n > self.CHUNK:
             ent = self._chunks[key] = [torch.zeros(self.CHUNK, dtype=torch.float64, device=device), 0]

@@ -1,5 +1,8 @@
-"""CPU: the counted-wait kernels keep their waits after compilation (tools/check_counted_waits.py).  Results never depend on
-it -- a compiler that adds waits only slows the kernels down -- so this is a performance regression guard on the BUILT library."""
+"""CPU: the counted-wait kernels keep their waits after compilation (tools/check_counted_waits.py).  Two guards on the BUILT
+library: a performance one (a compiler that adds `vmcnt(0)` waits only slows the kernels down) and a CORRECTNESS one -- no instruction may read
+the destination of one of the kernels' untracked inline-asm register loads before a `vmcnt` wait has retired that load (all vector-memory
+operations are tracked in issue order; `vmcnt(N)` keeps the N youngest pending), which a compiler-inserted copy or spill of such a register
+would violate."""
 import os
 import subprocess
 import sys

@@ -4,7 +4,9 @@ things the compiler is free to change: that it leaves the `s_waitcnt vmcnt(N)` o
 `vmcnt(0)` inside the tile loop (it does for LDS reads without a TBAA tag and for tracked global loads once LDS-DMAs are interleaved).  This
 script disassembles the gfx950 code objects of libslu_hip.so and reports, per instantiation, the vmcnt values in the tile loop; it exits
 non-zero when a loop contains more `vmcnt(0)` than the first-tile branches account for, or when an instruction reads the destination of
-one of the kernels' untracked (inline-asm) register loads before a vmcnt wait (that one WOULD be a wrong result).
+one of the kernels' untracked (inline-asm) register loads before a vmcnt wait has RETIRED that load (that one WOULD be a wrong result): all
+vector-memory operations are tracked in issue order and `vmcnt(N)` retires all but the N youngest, so a compiler-inserted move or spill of such
+a register behind a counted wait with N > 0 is caught too.  The scan is linear over the disassembly (not branch-aware).
 
     python tools/check_counted_waits.py [path/to/libslu_hip.so]
 """
@@ -28,7 +30,14 @@ with tempfile.TemporaryDirectory() as tmp:
         if "amdgcn" not in f:
             continue
         asm = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
-        name, waits, nbar, pending = None, [], 0, set()
+        name, waits, nbar = None, [], 0
+        vm_ops = []        # vector-memory operations issued so far in program order: the destination registers of an untracked register
+                           # load, or an empty set for anything else that counts in vmcnt (stores, LDS-DMA, tracked loads, atomics)
+        def pending_regs():
+            r = set()
+            for regs in vm_ops:
+                r |= regs
+            return r
         def flush():
             global bad
             if name is None:
@@ -48,33 +57,40 @@ with tempfile.TemporaryDirectory() as tmp:
                 flush()
                 name = m.group(1) if ("tail2_h8_kernel" in m.group(1) or "ring3_h8_kernel" in m.group(1)) else None
                 waits, nbar = [], 0
-                pending.clear()
+                vm_ops.clear()
                 continue
             if name is None:
                 continue
-            w = re.search(r"s_waitcnt\s+vmcnt\((\d+)\)", line)
-            if w:
-                waits.append(int(w.group(1)))
-                pending.clear()                            # every register load issued so far is covered by (or older than) a wait
-            if "s_barrier" in line:
-                nbar += 1
-            # the untracked register loads (inline asm, SGPR base + VGPR offset): nothing may read their destination before a vmcnt wait
             ins = line.split("//")[0]
+            w = re.search(r"s_waitcnt\s+vmcnt\((\d+)\)", ins)
+            if w:
+                n = int(w.group(1))
+                waits.append(n)
+                # vmcnt(N) retires everything but the N YOUNGEST vector-memory operations: their destinations stay pending
+                del vm_ops[:max(0, len(vm_ops) - n)]
+            if "s_barrier" in ins:
+                nbar += 1
+            # the untracked register loads (inline asm, SGPR base + VGPR offset): nothing may read their destination before a wait retires them
             m2 = re.search(r"global_load_dwordx[24]\s+v\[(\d+):(\d+)\],\s*v\d+,\s*s\[", ins)
             if m2:
-                pending.update(range(int(m2.group(1)), int(m2.group(2)) + 1))
+                vm_ops.append(set(range(int(m2.group(1)), int(m2.group(2)) + 1)))
                 continue
-            if pending and "global_load" not in ins:
+            if re.search(r"\b(global_load|global_store|global_atomic|buffer_load|buffer_store|buffer_atomic|scratch_load|scratch_store)", ins):
+                vm_ops.append(set())                       # counts in vmcnt, holds no untracked destination
+                continue
+            pend = pending_regs()
+            if pend:
                 ops = ins.strip().split(None, 1)
                 srcs = ops[1].split(",", 1)[1] if len(ops) > 1 and "," in ops[1] else ""
-                if ops and ops[0].startswith(("global_store", "ds_write", "v_mfma", "s_")):
-                    srcs = ops[1] if len(ops) > 1 else ""       # no destination operand first (stores) / accumulate in place
+                if ops and ops[0].startswith(("ds_write", "v_mfma", "s_")):
+                    srcs = ops[1] if len(ops) > 1 else ""       # no destination operand first / accumulate in place
                 used = set()
                 for a, b, c in re.findall(r"v\[(\d+):(\d+)\]|\bv(\d+)\b", srcs):
                     used.update(range(int(a), int(b) + 1) if a else [int(c)])
-                if used & pending:
-                    print(f"{name[:90]}: {ins.strip()[:80]}   <-- reads a register of an untracked load before any vmcnt wait")
+                if used & pend:
+                    print(f"{name[:90]}: {ins.strip()[:80]}   <-- reads a register of an untracked load that no vmcnt wait has retired yet")
                     bad += 1
-                    pending.clear()
+                    for regs in vm_ops:
+                        regs -= used
         flush()
 sys.exit(1 if bad else 0)
