@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 27
+#define SLU_ABI_VERSION 28
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -561,7 +561,11 @@ int slu_dropout_draw(const slu_dropout_site* sites, int nsites, const slu_dropou
  *   x [N][C][H][W] -> y [N][C][ceil(H/stride)][ceil(W/stride)].
  * slu_global_avgpool: mean over H W -> out [N][C] (SqueezeExcitation.avgpool).
  * slu_se_gate: scale [N][C] = sigmoid(w2 [C][S] . SiLU(w1 [S][C] . avg + b1) + b2)  (fc1 / fc2 of SqueezeExcitation are 1x1 convs on a 1x1 map);
- *   the scale reaches the block's projection conv as a per-(sample, channel) input multiplier (slu_conv_src.scale). */
+ *   the scale reaches the block's projection conv as a per-(sample, channel) input multiplier (slu_conv_src.scale).
+ * slu_dwconv3x3_wgrad (training, trainer.py:783-786 backward through the MBConv blocks): dw [C][9] = sum over (n, y, x) of dy[n][c][y][x] *
+ *   x[n][c][y + i - 1][x + j - 1] for the stride-1 depthwise conv (a stride-2 one is run as stride 1 + sub-sampling in training); the data
+ *   gradient is slu_dwconv3x3_fwd on dy with the nine taps reversed. */
+int slu_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, slu_stream_t stream);
 int slu_dwconv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int stride, int act, slu_stream_t stream);
 int slu_global_avgpool(const float* x, float* out, int N, int C, int HW, slu_stream_t stream);
 int slu_se_gate(const float* avg, const float* w1, const float* b1, const float* w2, const float* b2, float* scale, int N, int C, int S,

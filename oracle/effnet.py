@@ -4,7 +4,7 @@ torchvision (pinned 0.19.1, docker/Dockerfile:195) is absent from the build imag
 RESTATES the public architecture of torchvision.models.efficientnet for the V2 family: stem Conv2dNormActivation(3x3, stride 2, BatchNorm eps
 1e-3, SiLU); FusedMBConv (3x3 expansion conv + 1x1 projection, or a single 3x3 when the expansion ratio is 1); MBConv (1x1 expansion, depthwise
 3x3, SqueezeExcitation with squeeze = max(1, input // 4), SiLU / sigmoid, 1x1 projection); residual where stride 1 and equal channels;
-StochasticDepth = identity in eval mode.  **Block internals: parity unpinned** (no reference-held fixture).  What IS pinned, by the reference's
+StochasticDepth('row') = identity in eval mode, one Bernoulli draw per sample in train mode.  **Block internals: parity unpinned** (no reference-held fixture).  What IS pinned, by the reference's
 own class run through `torchvision_models_stub` (tools/gen_golden_r03.py effnet): which of these stages the model uses and how
 (semanticFCN_opt.py:238-247: features[0] with its conv replaced, features[2], [3], [4]; :396-404: the meta injection and
 x4 = cat(x3[:, :-m], meta3) -- layer4 = features[6:] is constructed and never called), the head and the state_dict layout."""
@@ -44,9 +44,14 @@ class SD(nn.Module):
         self.p, self.mode = p, mode
 
     def forward(self, x):
-        if self.training and self.p > 0.0:
-            raise NotImplementedError("oracle: StochasticDepth in train mode is not restated (inference oracle)")
-        return x
+        # torchvision.ops.stochastic_depth(input, p, 'row', training): one Bernoulli(1 - p) draw per sample, kept samples scaled by 1 / (1 - p)
+        if not self.training or self.p == 0.0:
+            return x
+        survival = 1.0 - self.p
+        noise = torch.empty([x.shape[0]] + [1] * (x.ndim - 1), dtype=x.dtype, device=x.device).bernoulli_(survival)
+        if survival > 0.0:
+            noise.div_(survival)
+        return x * noise
 
 
 class FusedMBConvRef(nn.Module):

@@ -5,6 +5,8 @@
 //   dwconv3x3_kernel      depthwise 3x3 (stride 1 / 2) + folded BatchNorm + SiLU: one lane per output pixel, lanes azimuth-adjacent
 //   global_avgpool_kernel SqueezeExcitation's AdaptiveAvgPool2d(1): one wave per (sample, channel) plane
 //   se_gate_kernel        fc1 -> SiLU -> fc2 -> sigmoid on the pooled vector: one workgroup per sample (<= 1536 channels x <= 96 squeezed)
+//   dwconv3x3_wgrad_kernel  training: dL/dw[c][tap] = sum over (sample, pixel) of dy * shifted x -- one workgroup per channel, nine fp64 block sums
+//                           (the data gradient of the stride-1 depthwise conv is the forward kernel with the taps reversed)
 #include "slu_common.h"
 
 namespace {
@@ -71,6 +73,47 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   }
 }
 
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int N,
+                                                              int C, int H, int W) {
+  const int c = blockIdx.x;
+  const size_t HW = (size_t)H * W;
+  double acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* px = x + ((size_t)n * C + c) * HW;
+    const float* pg = dy + ((size_t)n * C + c) * HW;
+    float part[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) part[t] = 0.0f;
+    for (size_t e = threadIdx.x; e < HW; e += blockDim.x) {
+      const int xx = (int)(e % W), yy = (int)(e / W);
+      const float g = pg[e];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int iy = yy + i - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int ix = xx + j - 1;
+          if (ix >= 0 && ix < W) part[i * 3 + j] = fmaf(g, px[(size_t)iy * W + ix], part[i * 3 + j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] += (double)part[t];      // fp32 within one plane and lane (<= HW / 256 terms), fp64 across planes and lanes
+  }
+  __shared__ double s_red[4][9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const double v = wave_sum(acc[t]);
+    if (lane == 0) s_red[wave][t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) dw[(size_t)c * 9 + threadIdx.x] = (float)(s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
 inline unsigned grid1d(size_t total) {
   const size_t nb = (total + 255) / 256;
   return (unsigned)(nb > 65535 ? 65535 : (nb ? nb : 1));
@@ -87,6 +130,12 @@ extern "C" int slu_dwconv3x3_fwd(const float* x, const float* w, const float* bi
     hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3(grid1d(total)), dim3(256), 0, slu_stream(stream), x, w, bias, y, N * C, C, H, W, OH, OW, act);
   else
     hipLaunchKernelGGL(dwconv3x3_kernel<2>, dim3(grid1d(total)), dim3(256), 0, slu_stream(stream), x, w, bias, y, N * C, C, H, W, OH, OW, act);
+  SLU_CHECK_LAUNCH();
+}
+
+extern "C" int slu_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, slu_stream_t stream) {
+  if (!x || !dy || !dw || N <= 0 || C <= 0 || H <= 0 || W <= 0) return SLU_EINVAL;
+  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((unsigned)C), dim3(256), 0, slu_stream(stream), x, dy, dw, N, C, H, W);
   SLU_CHECK_LAUNCH();
 }
 

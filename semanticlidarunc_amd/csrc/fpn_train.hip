@@ -1,7 +1,7 @@
 // Training path of the ResNet-FPN models (reference src/models/semanticFCN.py:266-354, src/baselines/Reichert/semanticFCN_opt.py:366-455;
 // the trainer calls loss.backward() on them, src/models/trainer.py:783-786): the per-pixel / data-movement kernels the autograd nodes of
 // semanticlidarunc_amd/fpn_autograd.py need besides the conv / BatchNorm machinery of backward.hip and wgrad.hip.  All HBM-bound, fp32.
-//   pointwise activations (ReLU / LeakyReLU, tanh, ELU + 1) forward and backward (from the OUTPUT, so no input is kept)
+//   pointwise activations (ReLU / LeakyReLU, tanh, ELU + 1; SiLU) forward and backward (from the OUTPUT, so no input is kept; SiLU: from the input)
 //   MaxPool2d(3, 2, 1) backward (gather form: every input pixel re-derives the arg-max of the <= 4 windows that contain it)
 //   nearest down-sampling backward, channel-tail replacement (x[:, -m:] = meta) forward / backward
 //   softmax-over-azimuth x value (AttentionModule) backward, depth-to-space (ConvTranspose2d as conv + rearrangement) backward
@@ -15,7 +15,7 @@ inline unsigned grid_for(size_t total, unsigned cap = 65536) {
   return (unsigned)(nb > cap ? cap : (nb ? nb : 1));
 }
 
-enum { OP_LEAKY = 0, OP_TANH = 1, OP_ELU1 = 2 };
+enum { OP_LEAKY = 0, OP_TANH = 1, OP_ELU1 = 2, OP_SILU = 3 };
 
 __global__ __launch_bounds__(256) void pointwise_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int op, float slope) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -23,12 +23,14 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(const float* __restr
     float r;
     if (op == OP_LEAKY) r = v > 0.0f ? v : v * slope;
     else if (op == OP_TANH) r = tanhf(v);
+    else if (op == OP_SILU) r = v / (1.0f + expf(-v));
     else r = (v > 0.0f ? v : expm1f(v)) + 1.0f;      // nn.ELU(alpha = 1) followed by the reference's "+ 1" (semanticFCN.py:352)
     y[e] = r;
   }
 }
 
-// dx = dy * f'(x) expressed through y = f(x): leaky: y > 0 ? 1 : slope (slope >= 0 keeps the sign); tanh: 1 - y^2; ELU + 1: y > 1 ? 1 : y
+// dx = dy * f'(x) expressed through y = f(x): leaky: y > 0 ? 1 : slope (slope >= 0 keeps the sign); tanh: 1 - y^2; ELU + 1: y > 1 ? 1 : y.
+// SiLU is not invertible from its output: there `y` is the forward's INPUT x, f'(x) = s (1 + x (1 - s)), s = sigmoid(x)
 __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, size_t n,
                                                             int op, float slope) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restr
     float d;
     if (op == OP_LEAKY) d = v > 0.0f ? 1.0f : slope;
     else if (op == OP_TANH) d = 1.0f - v * v;
+    else if (op == OP_SILU) { const float sg = 1.0f / (1.0f + expf(-v)); d = sg * (1.0f + v * (1.0f - sg)); }
     else d = v > 1.0f ? 1.0f : v;
     dx[e] = g * d;
   }
@@ -325,13 +328,13 @@ __global__ __launch_bounds__(1024) void spatial_gate_bwd_b_kernel(const float* _
 }  // namespace
 
 extern "C" int slu_pointwise_fwd(const float* x, float* y, size_t n, int op, float slope, slu_stream_t stream) {
-  if (!x || !y || n == 0 || op < 0 || op > 2 || (op == OP_LEAKY && !(slope >= 0.0f))) return SLU_EINVAL;
+  if (!x || !y || n == 0 || op < 0 || op > 3 || (op == OP_LEAKY && !(slope >= 0.0f))) return SLU_EINVAL;
   hipLaunchKernelGGL(pointwise_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, slu_stream(stream), x, y, n, op, slope);
   SLU_CHECK_LAUNCH();
 }
 
 extern "C" int slu_pointwise_bwd(const float* dy, const float* y, float* dx, size_t n, int op, float slope, slu_stream_t stream) {
-  if (!dy || !y || !dx || n == 0 || op < 0 || op > 2 || (op == OP_LEAKY && !(slope >= 0.0f))) return SLU_EINVAL;
+  if (!dy || !y || !dx || n == 0 || op < 0 || op > 3 || (op == OP_LEAKY && !(slope >= 0.0f))) return SLU_EINVAL;
   hipLaunchKernelGGL(pointwise_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, slu_stream(stream), dy, y, dx, n, op, slope);
   SLU_CHECK_LAUNCH();
 }

@@ -9,6 +9,8 @@ ResNet / FPN graphs need on top of it:
   batch_norm(...)        BatchNorm2d (train or eval statistics) [+ residual] on its own -- after a sub-sampled conv output
   relu / tanh / elu1     PointwiseFn
   max_pool / nearest_down / replace_tail / row_softmax_mul / depth_to_space / bilinear_up / group_norm / spatial_gate
+  silu / depthwise_conv3x3 / global_avg_pool / channel_gate / scale_add      the EfficientNetV2 blocks (MBConv: depthwise conv, squeeze-excitation;
+                                                                            StochasticDepth in train mode)
 """
 from __future__ import annotations
 
@@ -262,3 +264,103 @@ def _scale_nc(x, scale):
     channel axis."""
     n, c, h, w = x.shape
     return ops.affine(x.view(1, n * c, h, w), scale.reshape(n * c).contiguous().float(), None, None).view(n, c, h, w)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# EfficientNetV2 blocks (torchvision's FusedMBConv / MBConv; semanticFCN_opt.py:170-180,238-247,396-404 uses features[0], [2], [3], [4])
+# ---------------------------------------------------------------------------------------------------------------------------------------
+class SiluFn(torch.autograd.Function):
+    """x * sigmoid(x); the backward needs the INPUT (SiLU is not monotone, its output does not determine it)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.detach().contiguous()
+        ctx.save_for_backward(x)
+        return ops.pointwise_fwd(x, "silu")
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.pointwise_bwd(dy.contiguous().float(), x, "silu")
+
+
+def silu(x):
+    return SiluFn.apply(x)
+
+
+class DepthwiseConv3x3Fn(torch.autograd.Function):
+    """Depthwise 3x3 / stride 1 / pad 1, no bias: weight [C, 1, 3, 3].  Data gradient = the same kernel with the nine taps reversed."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.detach().contiguous()
+        w9 = weight.detach().float().reshape(weight.shape[0], 9).contiguous()
+        ctx.save_for_backward(x, w9)
+        return ops.dwconv3x3(x, w9, None, 1, "none")
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w9 = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        need = ctx.needs_input_grad
+        dx = ops.dwconv3x3(dy, w9.flip(1).contiguous(), None, 1, "none") if need[0] else None
+        dw = ops.dwconv3x3_wgrad(x, dy).view(-1, 1, 3, 3) if need[1] else None
+        return dx, dw
+
+
+class GlobalAvgPoolFn(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1) as [N, C] (SqueezeExcitation.avgpool)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (int(x.shape[2]), int(x.shape[3]))
+        return ops.global_avgpool(x.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, ds):
+        h, w = ctx.hw
+        n, c = ds.shape
+        return (ds.float() / float(h * w)).view(n, c, 1, 1).expand(n, c, h, w)      # a broadcast view: the engine's accumulation materialises it
+
+
+class ChannelGateFn(torch.autograd.Function):
+    """x * g[n, c] with a gradient for BOTH (SqueezeExcitation's `scale * input`)."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        x, g = x.detach().contiguous(), g.detach().contiguous().float()
+        ctx.save_for_backward(x, g)
+        return _scale_nc(x, g)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        need = ctx.needs_input_grad
+        n, c, h, w = x.shape
+        dx = _scale_nc(dy, g) if need[0] else None
+        dg = None
+        if need[1]:
+            # sum over H W of dy * x per (sample, channel): the BatchNorm-backward reduction with mean 0 / invstd 1 on the [1, N C, H, W] view
+            zero, one = torch.zeros(n * c, dtype=torch.float32, device=x.device), torch.ones(n * c, dtype=torch.float32, device=x.device)
+            _, s2 = ops.bn_bwd_reduce(dy.view(1, n * c, h, w), x.view(1, n * c, h, w), zero, one)
+            dg = s2.float().view(n, c)
+        return dx, dg
+
+
+class ScaleAddFn(torch.autograd.Function):
+    """y * noise[n] + x: torchvision's StochasticDepth('row') in train mode followed by the residual add (noise carries no gradient)."""
+
+    @staticmethod
+    def forward(ctx, y, noise_nc, x):
+        y, x = y.detach().contiguous(), x.detach().contiguous()
+        n, c, h, w = y.shape
+        ctx.save_for_backward(noise_nc)
+        return ops.affine(y.view(1, n * c, h, w), noise_nc.reshape(n * c).contiguous().float(), None, x.view(1, n * c, h, w)).view(n, c, h, w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (noise_nc,) = ctx.saved_tensors
+        dout = dout.contiguous().float()
+        need = ctx.needs_input_grad
+        return _scale_nc(dout, noise_nc) if need[0] else None, None, dout if need[2] else None

@@ -11,7 +11,8 @@ Same encoder as `fpn.SemanticNetworkWithFPN` (shared code); the head differs:
                               (`utils.mc_dropout`) works on this model, unlike on `models/semanticFCN.py` which has no dropout
   decoder (:286-296)          conv3x3 -> GN -> ReLU -> conv3x3 -> GN -> ReLU -> UpsampleBlock(x2) -> conv1x1: RAW LOGITS (no ELU)
 Contract kept: constructor keywords, `forward(x, meta) -> logits [B,num_classes,H,W]`, `state_dict` keys / shapes of the reference
-class (checked against it in tools/gen_golden_r02.py), genuine `nn.Dropout2d` / `nn.GroupNorm` children.  Inference only.
+class (checked against it in tools/gen_golden_r02.py), genuine `nn.Dropout2d` / `nn.GroupNorm` children.  Inference: folded launches
+(`_forward`); training / any gradient: one autograd node per layer (`_forward_train_opt`), ResNet and EfficientNetV2 encoders alike.
 """
 from __future__ import annotations
 
@@ -214,12 +215,89 @@ class SemanticNetworkWithFPN(_FPNBase):
         y = fa.conv2d([fa.BilinearUpFn.apply(x, up.scale)], conv.weight, None, 3, 1, 1, None, None, None, self._dg(name))
         return fa.group_norm(gn, y, relu_after=True)
 
+    # EfficientNetV2 encoder, training: the same blocks as _eff_block, one autograd node per layer, batch-statistics BatchNorm (eps 1e-3),
+    # StochasticDepth('row') live on the residual blocks (torchvision: `result = stochastic_depth(result); result += input`)
+    def _t_cna(self, name, cna, srcs, resid=None):
+        """Conv2dNormActivation (dense, stride 1): conv -> BatchNorm [+ resid] -> SiLU.  The residual form is only legal without activation (the
+        projection of a block): the one configuration that adds it AFTER the SiLU (a FusedMBConv with expansion 1) sits in features[1], which the
+        reference never calls."""
+        from . import fpn_autograd as fa
+        conv, bn = cna[0], cna[1]
+        if resid is not None and len(cna) > 2:
+            raise NotImplementedError("residual after the activation (FusedMBConv with expansion ratio 1) is not on the reference's path")
+        y = fa.conv2d(srcs, conv.weight, None, conv.kernel_size[0], conv.padding[0], 1, None, bn, resid, self._dg(name))
+        return fa.silu(y) if len(cna) > 2 else y
+
+    def _sd_noise(self, name, blk, n, c, device):
+        """[n, c] multipliers of torchvision's stochastic_depth(mode='row') for this block in train mode, None when it is the identity."""
+        sd = blk.stochastic_depth
+        if not sd.training or sd.p == 0.0:
+            return None
+        override = self.__dict__.get("_sd_noise_override")
+        if override is not None:
+            noise = override[name].to(device=device, dtype=torch.float32).reshape(n, 1)
+        else:
+            survival = 1.0 - sd.p
+            noise = torch.empty((n, 1), dtype=torch.float32, device=device).bernoulli_(survival)
+            if survival > 0.0:
+                noise.div_(survival)
+        return noise.expand(n, c).contiguous()
+
+    def _t_project(self, name, blk, proj, h, x):
+        """The block's last Conv2dNormActivation (no activation) + StochasticDepth + residual."""
+        from . import fpn_autograd as fa
+        if not blk.use_res_connect:
+            return self._t_cna(name, proj, [h])
+        noise = self._sd_noise(name.rsplit(".", 1)[0], blk, x.shape[0], proj[0].out_channels, x.device)
+        if noise is None:
+            return self._t_cna(name, proj, [h], resid=x)
+        return fa.ScaleAddFn.apply(self._t_cna(name, proj, [h]), noise, x)
+
+    def _t_eff_block(self, name, blk, x):
+        import torch.nn.functional as F
+        from . import fpn_autograd as fa
+        seq = blk.block
+        if isinstance(blk, _eff.FusedMBConv):
+            first = seq[0]
+            if len(seq) == 1:
+                raise NotImplementedError("FusedMBConv with expansion ratio 1 (features[1]) is not on the reference's path")
+            h = fa.silu(self._t_conv_s2(name + ".0", first[0], first[1], x)) if first[0].stride[0] == 2 else self._t_cna(name + ".0", first, [x])
+            return self._t_project(name + ".1", blk, seq[1], h, x)
+        i, h = 0, x
+        if len(seq) == 4:                                               # 1x1 expansion
+            h, i = self._t_cna(name + ".0", seq[0], [x]), 1
+        dw, se, proj = seq[i], seq[i + 1], seq[i + 2]
+        d = fa.DepthwiseConv3x3Fn.apply(h, dw[0].weight)
+        if dw[0].stride[0] == 2:
+            d = fa.NearestDownFn.apply(d, 2)                            # the stride-2 depthwise conv = the stride-1 one sampled at even pixels
+        d = fa.silu(fa.batch_norm(dw[1], d))
+        c, sq = se.fc1.in_channels, se.fc1.out_channels
+        pooled = fa.GlobalAvgPoolFn.apply(d)                            # [N, C]; the two tiny fully-connected layers run as library GEMMs
+        gate = torch.sigmoid(F.linear(F.silu(F.linear(pooled, se.fc1.weight.view(sq, c), se.fc1.bias)), se.fc2.weight.view(c, sq), se.fc2.bias))
+        return self._t_project(f"{name}.{i + 2}", blk, proj, fa.ChannelGateFn.apply(d, gate), x)
+
+    def _t_encode_effnet(self, x, meta):
+        from . import fpn_autograd as fa
+        if not self.multi_scale_meta:
+            raise NotImplementedError("efficientnet backbones run with multi_scale_meta=True only (the reference's other branch feeds layer4 = "
+                                      "features[6:] a tensor of the wrong channel count)")
+        m1, m2, m3 = (fa.NearestDownFn.apply(meta, f) for f in (2, 4, 8))
+        h = self._t_cna("stem", self.stem, [x, meta])
+        outs = []
+        for lname, stage, mk in (("layer1", self.layer1, None), ("layer2", self.layer2, m1), ("layer3", self.layer3, m2)):
+            if mk is not None:
+                h = fa.ReplaceTailFn.apply(h, mk)                       # :399-403: the stage sees cat(x[:, :-m], meta_k)
+            for bi, blk in enumerate(stage):
+                h = self._t_eff_block(f"{lname}.{bi}", blk, h)
+            outs.append(h)
+        return outs[0], outs[1], outs[2], fa.ReplaceTailFn.apply(outs[2], m3)      # :404: x4 = cat(x3[:, :-m], meta3) -- layer4 is never applied
+
     def _forward_train_opt(self, x, meta, drop_scale):
         from . import fpn_autograd as fa
         from . import autograd as _ag
         _ag.nbt_scope_enter()
         try:
-            x1, x2, x3, x4 = self._t_encode(x, meta)
+            x1, x2, x3, x4 = self._t_encode_effnet(x, meta) if self.is_effnet else self._t_encode(x, meta)
             f4 = self._t_cbr("fpn4", self.fpn_block4[0], self.fpn_block4[1], [x4])
             f3 = self._t_cbr("fpn3", self.fpn_block3[0], self.fpn_block3[1], [x3])
             f2 = self._t_cbr("fpn2", self.fpn_block2[0], self.fpn_block2[1], [x2])
@@ -247,12 +325,10 @@ class SemanticNetworkWithFPN(_FPNBase):
 
     def _forward(self, x, meta_channel, drop_scale):
         x, meta = self._check_inputs(x, meta_channel)
-        if self.is_effnet:
-            if any(isinstance(mod, nn.modules.batchnorm._BatchNorm) and mod.training for mod in self.modules()):
-                raise NotImplementedError("the EfficientNetV2 encoder runs in eval mode only on the HIP path (no training path yet); call .eval()")
-            x1, x2, x3, x4 = self._encode_effnet(x, meta)
-        elif self._wants_autograd(x, meta):
+        if self._wants_autograd(x, meta):
             return self._forward_train_opt(x, meta, drop_scale)
+        if self.is_effnet:
+            x1, x2, x3, x4 = self._encode_effnet(x, meta)
         else:
             x1, x2, x3, x4 = self._encode(x, meta)
         f4 = self._conv("fpn4", self.fpn_block4[0], self.fpn_block4[1], [ConvSource(x4)])

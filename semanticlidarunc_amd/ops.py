@@ -830,11 +830,11 @@ def spatial_softmax_gate(x: torch.Tensor, score: torch.Tensor, return_stats: boo
 # ------------------------------------------------------------------------------------------------
 # training path of the FPN models (csrc/fpn_train.hip): forward / backward pieces of the autograd nodes in fpn_autograd.py
 # ------------------------------------------------------------------------------------------------
-POINTWISE_OPS = {"leaky": 0, "tanh": 1, "elu+1": 2}
+POINTWISE_OPS = {"leaky": 0, "tanh": 1, "elu+1": 2, "silu": 3}
 
 
 def pointwise_fwd(x: torch.Tensor, op: str, slope: float = 0.0) -> torch.Tensor:
-    """LeakyReLU(slope) (0 = ReLU) / tanh / ELU + 1, elementwise."""
+    """LeakyReLU(slope) (0 = ReLU) / tanh / ELU + 1 / SiLU, elementwise."""
     _req(x, "x")
     y = torch.empty_like(x)
     if x.numel():
@@ -843,7 +843,7 @@ def pointwise_fwd(x: torch.Tensor, op: str, slope: float = 0.0) -> torch.Tensor:
 
 
 def pointwise_bwd(dy: torch.Tensor, y: torch.Tensor, op: str, slope: float = 0.0) -> torch.Tensor:
-    """dx = dy * f'(x), from the forward's output y."""
+    """dx = dy * f'(x), from the forward's output y (op 'silu': from the forward's INPUT, passed as `y`)."""
     _req(dy, "dy")
     _req(y, "y")
     if dy.shape != y.shape:
@@ -1342,6 +1342,27 @@ def dwconv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], st
     check(_lib.load().slu_dwconv3x3_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, c, h, wd, int(stride), {"none": 0, "silu": 3}[act],
                                         _stream()), "slu_dwconv3x3_fwd")
     return y
+
+
+def dwconv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """dL/dw [C, 9] of the stride-1 depthwise 3x3 conv y = dwconv3x3(x, w)."""
+    _req(x, "x")
+    _req(dy, "dy")
+    if x.shape != dy.shape:
+        raise RuntimeError("dwconv3x3_wgrad: x / dy shape mismatch")
+    n, c, h, w = x.shape
+    dw = torch.empty((c, 9), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_dwconv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, c, h, w, _stream()), "slu_dwconv3x3_wgrad")
+    return dw
+
+
+def global_avgpool(x: torch.Tensor) -> torch.Tensor:
+    """mean over H W -> [N, C]."""
+    _req(x, "x")
+    n, c, h, w = x.shape
+    avg = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    check(_lib.load().slu_global_avgpool(x.data_ptr(), avg.data_ptr(), n, c, h * w, _stream()), "slu_global_avgpool")
+    return avg
 
 
 def se_scale(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, b2: Optional[torch.Tensor]) -> torch.Tensor:

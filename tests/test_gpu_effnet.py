@@ -89,12 +89,8 @@ def test_efficientnet_fpn_opt_vs_oracle_at_another_size_and_dropout(cuda):
         model.to(cuda)
         got = model.forward_with_dropout_scale(x.to(cuda), meta.to(cuda), scale.to(cuda)).cpu()
     assert float((got - want).abs().max()) <= 1e-3 * max(1.0, float(want.abs().max()))
-    # train mode is refused loudly (no EfficientNet training path), MC-dropout mode (eval + live Dropout2d) works
-    model.train()
-    with pytest.raises(NotImplementedError):
-        model(x.to(cuda), meta.to(cuda))
+    # MC-dropout mode (eval + live Dropout2d) works on the folded inference path (the training path: tests/test_gpu_fpn_train.py)
     from semanticlidarunc_amd.utils.mc_dropout import set_dropout_mode
-    model.eval()
     set_dropout_mode(model, True)
     with torch.no_grad():
         a, b = model(x.to(cuda), meta.to(cuda)), model(x.to(cuda), meta.to(cuda))

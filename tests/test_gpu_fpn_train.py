@@ -115,6 +115,32 @@ def test_norm_and_gate_nodes(cuda):
             assert int(bn_g.num_batches_tracked) == int(bn_c.num_batches_tracked)
 
 
+def test_efficientnet_block_nodes(cuda):
+    """SiLU, depthwise 3x3 (data + weight gradient), SqueezeExcitation's pooling / gating, StochasticDepth + residual."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 24, 9, 40, generator=g) * 2
+    _check_node(fa.silu, F.silu, [x], cuda, tol=2e-6, grad_tol=1e-5)
+    for (n, c, h, w) in ((2, 24, 9, 40), (3, 130, 4, 16)):
+        xx, wt = torch.randn(n, c, h, w, generator=g), torch.randn(c, 1, 3, 3, generator=g) * 0.3
+        _check_node(lambda a, b: fa.DepthwiseConv3x3Fn.apply(a, b), lambda a, b: F.conv2d(a, b, None, padding=1, groups=c), [xx, wt], cuda, tol=2e-6,
+                    grad_tol=2e-5)
+    _check_node(lambda a: fa.GlobalAvgPoolFn.apply(a), lambda a: a.mean((2, 3)), [x], cuda, tol=2e-6)
+    gate = torch.rand(2, 24, generator=g)
+    _check_node(lambda a, b: fa.ChannelGateFn.apply(a, b), lambda a, b: a * b.view(2, 24, 1, 1), [x, gate], cuda, tol=2e-6, grad_tol=2e-5)
+    noise = (torch.tensor([0.0, 1.0 / 0.8]).view(2, 1).expand(2, 24)).contiguous()
+    r = torch.randn(2, 24, 9, 40, generator=g)
+    yc, rc = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    yg, rg = x.clone().to(cuda).requires_grad_(True), r.clone().to(cuda).requires_grad_(True)
+    oc = yc * noise.view(2, 24, 1, 1) + rc
+    og = fa.ScaleAddFn.apply(yg, noise.to(cuda), rg)
+    assert float((og.detach().cpu() - oc.detach()).abs().max()) <= 1e-6
+    cot = torch.randn(oc.shape, generator=g)
+    oc.backward(cot)
+    og.backward(cot.to(cuda))
+    assert float((yg.grad.cpu() - yc.grad).abs().max()) <= 1e-6 and float((rg.grad.cpu() - rc.grad).abs().max()) <= 1e-6
+    assert float(yg.grad[0].abs().max()) == 0.0                      # the dropped sample gets no gradient through the block
+
+
 def _bar(err, err_ref, scale, sens=0.0):
     """HIP error vs the float64 run: <= 4x the reference's own fp32 error, 4x the reference graph's own response to 1e-6-sized perturbations of
     its inputs and parameters (ReLU masks of near-zero pre-activations flip; tools/gen_golden_r03.py measures it), or 1e-3 of the scale"""
@@ -232,6 +258,56 @@ def test_opt_training_step_vs_the_reference_class(cuda):
     # the real Dropout2d child draws when no multiplier is given, and MC-dropout mode (eval + live dropout) still takes the inference path
     out2 = model(x, meta)
     assert out2.requires_grad and not torch.equal(out2, out)
+
+
+def test_efficientnet_training_step_vs_the_reference_class(cuda):
+    """The shipped YAML's model family (`model_type: efficientnet_v2_l`, configs/SemanticKitti_default.yaml:14; the fixture uses _s): one training
+    step of the reference's own class -- train-mode BatchNorm (eps 1e-3), depthwise convs, squeeze-excitation, SiLU, StochasticDepth on the
+    residual blocks with a pinned noise that drops samples, pyramid dropout pinned."""
+    import os
+    from conftest import GOLDEN
+    from semanticlidarunc_amd.fpn_opt import SemanticNetworkWithFPN as OptFPN
+    tag, kw = "fpn_opt_train_efficientnet_v2_s_m3_c20", dict(backbone="efficientnet_v2_s", input_channels=2, meta_channel_dim=3, num_classes=20)
+    gold = golden(tag)
+    scale = _t(np.load(os.path.join(GOLDEN, "fpn_opt_train_efficientnet_v2_s_dropout_scale.npy")))
+    noise = {k: _t(v) for k, v in np.load(os.path.join(GOLDEN, "fpn_opt_train_efficientnet_v2_s_sd_noise.npz")).items()}
+    torch.manual_seed(0)
+    model = randomize_bn_(OptFPN(**kw), 3)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(9)
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.GroupNorm):
+                mod.weight.copy_(torch.rand(mod.num_channels, generator=g) + 0.5)
+                mod.bias.copy_(torch.randn(mod.num_channels, generator=g) * 0.1)
+    model = model.to(cuda).train()
+    model._sd_noise_override = noise
+    x, meta = _t(gold["x"]).to(cuda).requires_grad_(True), _t(gold["meta"]).to(cuda).requires_grad_(True)
+    R = _t(gold["R"]).to(cuda)
+    out = model.forward_with_dropout_scale(x, meta, scale.to(cuda))
+    loss = (out * R).sum()
+    params = dict(model.named_parameters())
+    names = [str(n) for n in gold["grad_names"]]
+    assert names == list(params)
+    grads = torch.autograd.grad(loss, [params[n] for n in names] + [x, meta], allow_unused=True)
+    _check_against_fixture(gold, names, out, grads)
+    for key in gold.files:
+        if key.startswith("bn64:"):
+            want, got = _t(gold[key]), dict(model.named_buffers())[key[5:]].cpu()
+            if want.is_floating_point():
+                assert float((got.double() - want.double()).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), key
+            else:
+                assert int(got) == int(want), key
+    # live StochasticDepth: the model draws its own noise when none is pinned
+    del model._sd_noise_override
+    a = model.forward_with_dropout_scale(x, meta, scale.to(cuda))
+    b = model.forward_with_dropout_scale(x, meta, scale.to(cuda))
+    assert a.requires_grad and not torch.equal(a, b)
+    # eval mode with gradients: StochasticDepth is the identity and the autograd path reproduces the folded inference launches
+    model.eval()
+    with torch.no_grad():
+        want = model.forward_with_dropout_scale(x.detach(), meta.detach(), scale.to(cuda))
+    got = model.forward_with_dropout_scale(x, meta, scale.to(cuda))
+    assert got.requires_grad and float((got.detach() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
 
 
 def test_eval_mode_with_gradients_equals_the_folded_inference_path(cuda):

@@ -2,7 +2,7 @@
 """Round-3 additions to the pinned fixtures: same rules as tools/gen_golden.py (runs ONLY in the build container, imports the reference
 read-only from /root/reference, writes small data-only fixtures under tests/golden/).
 
-    python tools/gen_golden_r03.py [fpn_train] [fpn_opt_train] [effnet]
+    python tools/gen_golden_r03.py [fpn_train] [fpn_opt_train] [effnet] [effnet_train]
 
 fpn_train / fpn_opt_train: one TRAINING step of the reference's own classes (models/semanticFCN.py, baselines/Reichert/semanticFCN_opt.py) in
 train mode -- batch-statistics BatchNorm, running-statistics update, loss = sum(out * R), backward -- through the stub torchvision.models that
@@ -226,7 +226,65 @@ def gen_effnet():
         json.dump({k: list(v.shape) for k, v in RefOpt("efficientnet_v2_s", 2, 3, num_classes=20).state_dict().items()}, f, indent=0)
 
 
+def gen_effnet_train():
+    """One TRAINING step of the reference's semanticFCN_opt with the efficientnet_v2_s backbone (train-mode BatchNorm eps 1e-3, depthwise conv,
+    squeeze-excitation, SiLU, StochasticDepth on the residual blocks) through the stub torchvision.models.  The two random draws are pinned: the
+    pyramid Dropout2d by a fixed multiplier, StochasticDepth by a fixed per-(block, sample) noise (stored; it contains dropped samples)."""
+    _stub_torchvision()
+    from baselines.Reichert.semanticFCN_opt import SemanticNetworkWithFPN as RefOpt
+    from oracle import effnet as oeff
+    from semanticlidarunc_amd.fpn_opt import SemanticNetworkWithFPN as MyOpt
+    kw = dict(backbone="efficientnet_v2_s", input_channels=2, meta_channel_dim=3, num_classes=20)
+    shape = (2, 32, 128)
+    gd = torch.Generator().manual_seed(78)
+    probe = RefOpt(**kw)
+    cpyr = probe.decoder_semantic[0].in_channels
+    scale = (torch.rand(shape[0], cpyr, 1, 1, generator=gd) > 0.1).float() / 0.9
+    stages = (("layer1", 2), ("layer2", 3), ("layer3", 4))
+    noise = {}
+    for lname, fi in stages:
+        for bi, blk in enumerate(probe.backbone.features[fi]):
+            p = blk.stochastic_depth.p
+            # torchvision's draw, but with an inflated drop rate for the stored pattern (p <= 0.05 here would leave every sample alive): the
+            # multiplier of a kept sample stays the block's own 1 / (1 - p)
+            keep = (torch.rand(shape[0], generator=gd) > 0.3).float()
+            noise[f"{lname}.{bi}"] = keep / (1.0 - p) if p > 0.0 else torch.ones(shape[0])
+    assert any(float(v.min()) == 0.0 for v in noise.values())
+
+    def fix_random(ref, dtype):
+        class Fixed(torch.nn.Module):
+            def forward(self, t):
+                return t * scale.to(t.dtype)
+
+        class FixedSD(torch.nn.Module):
+            def __init__(self, v, p):
+                super().__init__()
+                self.v, self.p = v, p
+
+            def forward(self, t):
+                return t * self.v.to(t.dtype).view(-1, 1, 1, 1) if (self.training and self.p > 0.0) else t
+        for name, mod in list(ref.named_children()):
+            if isinstance(mod, torch.nn.Dropout2d):
+                setattr(ref, name, Fixed())
+        for lname, fi in stages:
+            for bi, blk in enumerate(ref.backbone.features[fi]):
+                assert isinstance(blk.stochastic_depth, oeff.SD)
+                blk.stochastic_depth = FixedSD(noise[f"{lname}.{bi}"], blk.stochastic_depth.p)
+    names = [n for n, _ in probe.named_parameters()]
+    want = ["backbone.features.0.0.weight", "backbone.features.0.1.weight", "backbone.features.2.0.block.0.0.weight", "backbone.features.2.3.block.1.0.weight",
+            "backbone.features.3.0.block.0.0.weight", "backbone.features.3.1.block.1.1.bias", "backbone.features.4.0.block.0.0.weight",
+            "backbone.features.4.0.block.1.0.weight", "backbone.features.4.0.block.1.1.weight", "backbone.features.4.0.block.2.fc1.weight",
+            "backbone.features.4.0.block.2.fc1.bias", "backbone.features.4.0.block.2.fc2.weight", "backbone.features.4.0.block.2.fc2.bias",
+            "backbone.features.4.0.block.3.0.weight", "backbone.features.4.2.block.1.0.weight", "backbone.features.4.5.block.3.1.weight"]
+    assert all(n in names for n in want), [n for n in want if n not in names]
+    want += [n for n in names if n.startswith(("attention", "upsample", "decoder_semantic", "fpn_block1"))][:10]
+    _fixture("fpn_opt_train_efficientnet_v2_s_m3_c20", RefOpt, MyOpt, kw, shape, want,
+             ["backbone.features.4.0.block.1.1", "backbone.features.2.0.block.0.1"], fix_random)
+    np.save(os.path.join(OUT, "fpn_opt_train_efficientnet_v2_s_dropout_scale.npy"), scale.numpy())
+    np.savez(os.path.join(OUT, "fpn_opt_train_efficientnet_v2_s_sd_noise.npz"), **{k: v.numpy() for k, v in noise.items()})
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["fpn_train"]
     for w in what:
-        {"fpn_train": gen_fpn_train, "fpn_opt_train": gen_fpn_opt_train, "effnet": gen_effnet}[w]()
+        {"fpn_train": gen_fpn_train, "fpn_opt_train": gen_fpn_opt_train, "effnet": gen_effnet, "effnet_train": gen_effnet_train}[w]()

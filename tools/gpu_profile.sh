@@ -5,9 +5,10 @@ set -eo pipefail
 OUT=${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+sha256sum semanticlidarunc_amd/libslu_hip.so > "$OUT/libslu_hip.sha256"    # every number below comes from THIS build
 echo "[1/6] bench.py (default)"; timeout -k 10 600 python bench.py --breakdown "$OUT/bench_f16_conv_breakdown_hipevents.txt" > "$OUT/bench_f16_line.json" 2> "$OUT/bench_f16.err"
 tail -c 600 "$OUT/bench_f16_line.json"; echo
-echo "[2/6] rocprofv3 --kernel-trace --stats"; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py --no-cpu-baseline --no-train-step > "$OUT/bench_f16_line_under_rocprof.json" 2> "$OUT/rocprof_stats.err"
+echo "[2/6] rocprofv3 --kernel-trace --stats"; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py --no-cpu-baseline --no-train-step --no-shared-prefix > "$OUT/bench_f16_line_under_rocprof.json" 2> "$OUT/rocprof_stats.err"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_f16_kernel_stats.csv"
 echo "[3/6] PMC FETCH_SIZE"; SLU_CONV_PRECISION=f16 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_rd" -- python3 tools/prof_forward.py 64 2 mc > "$OUT/pmc_rd.log" 2>&1
 echo "[4/6] PMC WRITE_SIZE"; SLU_CONV_PRECISION=f16 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_wr" -- python3 tools/prof_forward.py 64 2 mc > "$OUT/pmc_wr.log" 2>&1
