@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 28
+#define SLU_ABI_VERSION 30
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -187,15 +187,17 @@ int slu_softmax_loss_bwd(const float* probs, const int64_t* labels, const float*
                          const float* gout, int B, int C, int HW, float* grad_logits, slu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * Lovasz-Softmax, classes='present' (losses/lovasz.py:12-88).  probs [B,C,HW] (rows sum to 1), labels int64 [B,HW];
+ * Lovasz-Softmax (losses/lovasz.py:12-88).  probs [B,C,HW] (rows sum to 1), labels int64 [B,HW];
  * pixels with label == ignore_index are dropped (pass INT64_MIN for none).
- *   loss[1]      : mean over present classes of  sum_k err_(k) * (J_k - J_{k-1})   (errors sorted descending)
- *   n_present[1] : number of present classes (float)
+ * class_mask: 0 = classes='present' (the classes that occur among the valid labels); else bit c set = class c is summed whether it occurs
+ *   or not (classes='all': all C bits; classes=[...]: those) -- an absent class contributes its largest probability (lovasz.py:62-75).
+ *   loss[1]      : mean over the summed classes of  sum_k err_(k) * (J_k - J_{k-1})   (errors sorted descending)
+ *   n_present[1] : number of summed classes (float)
  *   grad_probs   : [B,C,HW] d loss / d probs, or NULL
  * workspace: slu_lovasz_workspace_bytes(B,C,HW) bytes, 256-byte aligned, caller-owned scratch.
  * ------------------------------------------------------------------------------------------ */
 size_t slu_lovasz_workspace_bytes(int B, int C, int HW);
-int slu_lovasz_fwd(const float* probs, const int64_t* labels, int B, int C, int HW, int64_t ignore_index,
+int slu_lovasz_fwd(const float* probs, const int64_t* labels, int B, int C, int HW, int64_t ignore_index, unsigned class_mask,
                    void* workspace, size_t workspace_bytes, float* loss, float* n_present, float* grad_probs,
                    slu_stream_t stream);
 
@@ -243,13 +245,15 @@ int slu_conv2d_wgrad(const float* da_t, const float* in_t, int N, int H, int W, 
                      float* dWp, float* dW, slu_stream_t stream);
 /* weight gradient of a 1x1 conv straight from the NCHW tensors (no channel-last copies): da [N,Cout,HW], the conv's sources as in
  * slu_conv2d_fwd (plain tensors only: no PixelShuffle / multiplier / broadcast; every source but the last a multiple of 32 channels; HW a
- * multiple of 32; 16-byte aligned bases) -> dW [Cout, sum of source channels].  SLU_EUNSUPPORTED otherwise (use slu_conv2d_wgrad). */
-int slu_conv1x1_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int HW, int Cout, float* dW, slu_stream_t stream);
+ * multiple of 32; 16-byte aligned bases) -> dW [Cout, sum of source channels].  SLU_EUNSUPPORTED otherwise (use slu_conv2d_wgrad).
+ * prezeroed != 0: the caller hands over an accumulator that is already zero (dW here, dWp below) and the launcher skips its fill -- a
+ * training step issues ~50 of these calls, one fill each was 0.2 ms of it. */
+int slu_conv1x1_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int HW, int Cout, float* dW, int prezeroed, slu_stream_t stream);
 /* the 3x3 (dil 1 / 2, pad = dil) and 2x2 (dil 2, pad 1) families: da [N,Cout,H,W]; sources as in slu_conv2d_fwd including PixelShuffle and
  * multipliers (no broadcast / channel cut), any channel counts; W a multiple of 16 (PixelShuffle sources: H even);
  * dWp: scratch of slu_wgrad_packed_floats floats -> dW [Cout, Cin, k, k].  SLU_EUNSUPPORTED otherwise (use slu_conv2d_wgrad). */
 int slu_conv2d_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int H, int W, int Cout, int ksize, int dil, int pad,
-                          float* dWp, float* dW, slu_stream_t stream);
+                          float* dWp, float* dW, int prezeroed, slu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * ResNet-FPN pieces (models/semanticFCN.py:145-153, 230-245, 266-354): data movement around the conv kernel.
@@ -497,6 +501,10 @@ int slu_spherical_projection_ex(const double* pc, int N, int C, int H, int W, in
  *   range [H][W] = |xyz|, reflectivity [H][W], xyz [3][H][W], normals_chw [3][H][W], labels int64 [H][W] (:83-99). */
 int slu_kitti_decode(const float* xyzi, const uint32_t* label, int N, const int32_t* lut, int lut_size, int rotate, double cos_a, double sin_a,
                      double* pc, int32_t* bad_count, slu_stream_t stream);
+/* SemanticKitti(resize=True) (dataloader_semantic_KITTI.py:61-62): cv2.resize(img, (OW, OH), interpolation=cv2.INTER_NEAREST) of the projected
+ * [H][W][C] image -- source index min(floor(dst * src_size / dst_size), src_size - 1) per axis, OpenCV's definition (cv2 is absent from the
+ * build image: unpinned like the normals); flip != 0: the dataloader's flip augmentation applied after it (:71-73). */
+int slu_resize_nearest_hwc(const float* img, int H, int W, int C, float* out, int OH, int OW, int flip, slu_stream_t stream);
 int slu_range_image_split(const float* img, const float* normals, int H, int W, int C, float* range, float* refl, float* xyz, float* normals_chw,
                           int64_t* labels, slu_stream_t stream);
 

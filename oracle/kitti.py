@@ -37,12 +37,24 @@ def decode(bin_bytes, label_bytes, id_map: dict):
     return np.concatenate([xyzi, mapped[..., np.newaxis]], axis=-1)
 
 
-def sample(bin_bytes, label_bytes, id_map: dict, projection=(64, 2048), rotate_angle=None, flip=False):
-    """-> (range [1,H,W] f32, reflectivity [1,H,W] f32, xyz [3,H,W] f32, normals [3,H,W] f32, semantics [1,H,W] int64): :51-99 without resize."""
+def resize_nearest(img, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_NEAREST) restated from OpenCV's definition (resizeNN: source index
+    min(floor(dst * src_size / dst_size), src_size - 1) per axis) -- cv2 is absent from this image: PARITY UNPINNED, like the normals."""
+    h, w = img.shape[:2]
+    ys = np.minimum(np.floor(np.arange(out_h) * (h / out_h)).astype(np.int64), h - 1)
+    xs = np.minimum(np.floor(np.arange(out_w) * (w / out_w)).astype(np.int64), w - 1)
+    return img[ys][:, xs]
+
+
+def sample(bin_bytes, label_bytes, id_map: dict, projection=(64, 2048), rotate_angle=None, flip=False, resize=None):
+    """-> (range [1,H,W] f32, reflectivity [1,H,W] f32, xyz [3,H,W] f32, normals [3,H,W] f32, semantics [1,H,W] int64): :51-99; resize: None
+    or the (rows, columns) of the dataloader's nearest resize (the reference fixes (128, 2048), :61-62)."""
     xyzil = decode(bin_bytes, label_bytes, id_map)
     if rotate_angle is not None:
         xyzil[..., 0:3] = rotate_z(xyzil[..., 0:3].reshape(-1, 3), float(rotate_angle))
     img, _, _, _ = oproj.spherical_projection(xyzil, projection[0], projection[1])
+    if resize is not None:
+        img = resize_nearest(img, resize[0], resize[1])
     if flip:
         img = img[:, ::-1, :]
         img[..., 1] *= -1

@@ -23,8 +23,9 @@ def jaccard_steps(fg_sorted: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def lovasz_softmax(probs: torch.Tensor, labels: torch.Tensor, ignore_index=None) -> torch.Tensor:
-    """probs [B,C,H,W] (rows sum to 1), labels [B,H,W] -> scalar; classes='present', mean."""
+def lovasz_softmax(probs: torch.Tensor, labels: torch.Tensor, ignore_index=None, classes="present") -> torch.Tensor:
+    """probs [B,C,H,W] (rows sum to 1), labels [B,H,W] -> scalar, mean over the summed classes (lovasz.py:56-88): classes='present' skips the
+    classes without a valid pixel; 'all' / a list sums them regardless (an absent class then contributes its largest probability)."""
     c = probs.size(1)
     flat = probs.movedim(1, -1).reshape(-1, c)
     y = labels.reshape(-1).long()
@@ -34,9 +35,9 @@ def lovasz_softmax(probs: torch.Tensor, labels: torch.Tensor, ignore_index=None)
     if flat.numel() == 0:
         return probs.new_tensor(0.0)
     per_class = []
-    for k in range(c):
+    for k in (range(c) if classes in ("all", "present") else classes):
         fg = (y == k).to(flat.dtype)
-        if fg.sum() == 0:
+        if classes == "present" and fg.sum() == 0:
             continue
         err = (fg - flat[:, k]).abs()
         err_sorted, order = torch.sort(err, descending=True)

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 28
+ABI_VERSION = 30
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -141,9 +141,9 @@ SIGNATURES = {
     "slu_wgrad_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "slu_conv2d_wgrad": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    c_f32p, c_f32p, c_stream]),
-    "slu_conv1x1_wgrad_nchw": (C.c_int, [c_f32p, C.POINTER(ConvSrc), C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "slu_conv1x1_wgrad_nchw": (C.c_int, [c_f32p, C.POINTER(ConvSrc), C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_stream]),
     "slu_conv2d_wgrad_nchw": (C.c_int, [c_f32p, C.POINTER(ConvSrc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
-                                        c_stream]),
+                                        C.c_int, c_stream]),
     "slu_maxpool3s2_fwd": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_nearest_down": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_space_to_depth2": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
@@ -218,8 +218,9 @@ SIGNATURES = {
     "slu_dwconv3x3_wgrad": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_global_avgpool": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_se_gate": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_resize_nearest_hwc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
     "slu_lovasz_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    "slu_lovasz_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_size_t, c_f32p,
+    "slu_lovasz_fwd": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint, C.c_void_p, C.c_size_t, c_f32p,
                                  c_f32p, c_f32p, c_stream]),
 }
 

@@ -542,6 +542,14 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
           auto read_frags = [&](int set, int ts) __attribute__((always_inline)) {
             const int j = ts / T, tap = ts % T;          // K-step of the chunk, tap
             const int dy = (tap / KS) * DIL, dx = (tap % KS) * DIL;
+#ifdef SLU_H8_FAKE_LDS      // experiment (WRONG results): a quarter of the fragment reads, the same MFMAs -- does LDS traffic limit these layers?
+            af[set][0] = __builtin_bit_cast(half8, sa[ts * 64]);
+            bf[set][0] = __builtin_bit_cast(half8, sb[j * 2 * REC + dy * LW + dx]);
+#pragma unroll
+            for (int i = 1; i < MB; ++i) af[set][i] = af[set][0];
+#pragma unroll
+            for (int b = 1; b < NB; ++b) bf[set][b] = bf[set][0];
+#else
 #pragma unroll
             for (int i = 0; i < MB; ++i) af[set][i] = __builtin_bit_cast(half8, sa[i * a_stride + ts * 64]);
 #pragma unroll
@@ -549,6 +557,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 8) ? 1 : ((WM * WN >= 8 
               bf[set][b] = __builtin_bit_cast(half8, sb[j * 2 * REC + ((b >> 1) + dy) * LW + (b & 1) * 32 + dx]);
               if constexpr (SCALED) bf[set][b] *= sc;
             }
+#endif
           };
           read_frags(0, 0);
 #pragma unroll

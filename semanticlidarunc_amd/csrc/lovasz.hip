@@ -34,6 +34,7 @@ struct Ws {
   unsigned* G;         // [C] foreground count per class (valid pixels)
   unsigned* blkfg;     // [C][nblk]
   double* loss_c;      // [C]
+  unsigned* act;       // [C] 1 = the class is summed whether or not it is present (classes='all' / an explicit list); unused for 'present'
 };
 
 __host__ __device__ inline int nblk_of(long long n) { return (int)((n + kTile - 1) / kTile); }
@@ -202,11 +203,13 @@ __device__ __forceinline__ float jaccard(unsigned G, unsigned long long k, unsig
 
 __global__ __launch_bounds__(kThreads) void lovasz_steps_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals,
                                                                 long long N, int nblk, const unsigned* __restrict__ G,
-                                                                const unsigned* __restrict__ blkfg, double* __restrict__ loss_c,
-                                                                float* __restrict__ grad /* [C][N] pixel order, or null */) {
+                                                                const unsigned* __restrict__ act, const unsigned* __restrict__ blkfg,
+                                                                double* __restrict__ loss_c, float* __restrict__ grad /* [C][N] pixel order, or null */) {
   const int c = blockIdx.y, blk = blockIdx.x;
+  // an ABSENT class that is summed anyway (g = 0, lovasz.py:66-69 with classes='all'): the Jaccard steps degenerate to (1, 0, 0, ...), the term is
+  // the largest error = max p_c and its gradient +1 at that pixel -- the formulas below give exactly that with g = 0
   const unsigned g = G[c];
-  if (g == 0) return;
+  if (act[c] == 0) return;
   __shared__ unsigned s_wave[kThreads / 64];
   __shared__ double s_part[kThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -257,7 +260,11 @@ __global__ __launch_bounds__(kThreads) void lovasz_steps_kernel(const unsigned* 
   }
 }
 
-// loss = mean over present classes; grad_probs[b][c][hw] = grad[c][b*HW+hw] / n_present (0 for absent classes)
+__global__ void lovasz_set_active_kernel(unsigned* __restrict__ act, int C, unsigned mask) {
+  if ((int)threadIdx.x < C) act[threadIdx.x] = (mask >> threadIdx.x) & 1u;
+}
+
+// loss = mean over the summed classes (G = the activity flags: the foreground counts for 'present'); grad_probs[b][c][hw] = grad[c][b*HW+hw] / n (0 for the others)
 __global__ void lovasz_finalize_kernel(const unsigned* __restrict__ G, const double* __restrict__ loss_c, int C,
                                        float* __restrict__ loss_out, float* __restrict__ n_present_out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -298,8 +305,9 @@ size_t carve(char* base, long long N, int C, Ws* ws) {
   char* v0 = take((size_t)C * N * 4); char* v1 = take((size_t)C * N * 4);
   char* h = take((size_t)C * 256 * nblk * 4);
   char* bf = take((size_t)C * nblk * 4);
+  char* ac = take((size_t)C * sizeof(unsigned));
   if (ws) {
-    ws->G = (unsigned*)g; ws->loss_c = (double*)l;
+    ws->G = (unsigned*)g; ws->loss_c = (double*)l; ws->act = (unsigned*)ac;
     ws->keys[0] = (unsigned*)k0; ws->keys[1] = (unsigned*)k1; ws->vals[0] = (unsigned*)v0; ws->vals[1] = (unsigned*)v1;
     ws->hist = (unsigned*)h; ws->blkfg = (unsigned*)bf;
   }
@@ -313,7 +321,7 @@ extern "C" size_t slu_lovasz_workspace_bytes(int B, int C, int HW) {
   return carve(nullptr, (long long)B * HW, C, nullptr);
 }
 
-extern "C" int slu_lovasz_fwd(const float* probs, const int64_t* labels, int B, int C, int HW, int64_t ignore_index,
+extern "C" int slu_lovasz_fwd(const float* probs, const int64_t* labels, int B, int C, int HW, int64_t ignore_index, unsigned class_mask,
                               void* workspace, size_t workspace_bytes, float* loss, float* n_present, float* grad_probs,
                               slu_stream_t stream) {
   if (!probs || !labels || !workspace || !loss || !n_present || B <= 0 || C <= 0 || HW <= 0) return SLU_EINVAL;
@@ -327,26 +335,32 @@ extern "C" int slu_lovasz_fwd(const float* probs, const int64_t* labels, int B, 
   if (hipMemsetAsync(ws.G, 0, align256((size_t)C * sizeof(unsigned)) + (size_t)C * sizeof(double), st) != hipSuccess) return SLU_ELAUNCH;
   const unsigned kg = (unsigned)((N + kThreads - 1) / kThreads > 1024 ? 1024 : (N + kThreads - 1) / kThreads);
   hipLaunchKernelGGL(keygen_kernel, dim3(kg, C), dim3(kThreads), 0, st, probs, labels, B, C, HW, ignore_index, ws.keys[0], ws.vals[0], ws.G);
+  // which classes are sorted and summed: the present ones (flag = foreground count), or the caller's set whether present or not
+  const unsigned* act = ws.G;
+  if (class_mask) {
+    hipLaunchKernelGGL(lovasz_set_active_kernel, dim3(1), dim3(64), 0, st, ws.act, C, class_mask);
+    act = ws.act;
+  }
   int cur = 0;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 8 * pass;
-    hipLaunchKernelGGL(hist_kernel, dim3(nblk, C), dim3(kThreads), 0, st, ws.keys[cur], N, nblk, shift, ws.G, ws.hist);
-    hipLaunchKernelGGL(scan_kernel, dim3(C), dim3(256), 0, st, ws.hist, nblk, ws.G);
+    hipLaunchKernelGGL(hist_kernel, dim3(nblk, C), dim3(kThreads), 0, st, ws.keys[cur], N, nblk, shift, act, ws.hist);
+    hipLaunchKernelGGL(scan_kernel, dim3(C), dim3(256), 0, st, ws.hist, nblk, act);
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk, C), dim3(kThreads), 0, st, ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1],
-                       ws.vals[cur ^ 1], N, nblk, shift, ws.G, ws.hist);
+                       ws.vals[cur ^ 1], N, nblk, shift, act, ws.hist);
     cur ^= 1;
   }
-  hipLaunchKernelGGL(fgcount_kernel, dim3(nblk, C), dim3(kThreads), 0, st, ws.vals[cur], N, nblk, ws.G, ws.blkfg);
-  hipLaunchKernelGGL(fgscan_kernel, dim3(C), dim3(256), 0, st, ws.blkfg, nblk, ws.G);
+  hipLaunchKernelGGL(fgcount_kernel, dim3(nblk, C), dim3(kThreads), 0, st, ws.vals[cur], N, nblk, act, ws.blkfg);
+  hipLaunchKernelGGL(fgscan_kernel, dim3(C), dim3(256), 0, st, ws.blkfg, nblk, act);
   // per-pixel gradient (class-major, pixel order) reuses the idle value buffer
   float* gtmp = grad_probs ? reinterpret_cast<float*>(ws.keys[cur ^ 1]) : nullptr;
-  hipLaunchKernelGGL(lovasz_steps_kernel, dim3(nblk, C), dim3(kThreads), 0, st, ws.keys[cur], ws.vals[cur], N, nblk, ws.G, ws.blkfg,
+  hipLaunchKernelGGL(lovasz_steps_kernel, dim3(nblk, C), dim3(kThreads), 0, st, ws.keys[cur], ws.vals[cur], N, nblk, ws.G, act, ws.blkfg,
                      ws.loss_c, gtmp);
-  hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(64), 0, st, ws.G, ws.loss_c, C, loss, n_present);
+  hipLaunchKernelGGL(lovasz_finalize_kernel, dim3(1), dim3(64), 0, st, act, ws.loss_c, C, loss, n_present);
   if (grad_probs) {
     const size_t total = (size_t)B * C * HW;
     const unsigned g = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(lovasz_grad_layout_kernel, dim3(g), dim3(256), 0, st, gtmp, ws.G, n_present, B, C, HW, grad_probs);
+    hipLaunchKernelGGL(lovasz_grad_layout_kernel, dim3(g), dim3(256), 0, st, gtmp, act, n_present, B, C, HW, grad_probs);
   }
   SLU_CHECK_LAUNCH();
 }

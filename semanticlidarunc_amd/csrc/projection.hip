@@ -236,7 +236,37 @@ __global__ __launch_bounds__(256) void range_image_split_kernel(const float* __r
   }
 }
 
+// cv2.resize(img, (OW, OH), interpolation=INTER_NEAREST) of an [H][W][C] image (dataloader_semantic_KITTI.py:61-62): OpenCV's nearest
+// neighbour takes source index min(floor(dst * (src_size / dst_size)), src_size - 1) per axis (the ratio in double precision); flip = the
+// dataloader's augmentation applied AFTER the resize (:71-73: columns reversed, y negated)
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ img, int H, int W, int C, float* __restrict__ out, int OH, int OW,
+                                                             double fy, double fx, int flip) {
+  const size_t total = (size_t)OH * OW * C;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const size_t px = e / C;
+    int ox = (int)(px % OW);
+    const int oy = (int)(px / OW);
+    if (flip) ox = OW - 1 - ox;
+    int sy = (int)floor((double)oy * fy), sx = (int)floor((double)ox * fx);
+    sy = sy < H - 1 ? sy : H - 1;
+    sx = sx < W - 1 ? sx : W - 1;
+    float v = img[((size_t)sy * W + sx) * C + c];
+    if (flip && c == 1) v = -v;
+    out[e] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int slu_resize_nearest_hwc(const float* img, int H, int W, int C, float* out, int OH, int OW, int flip, slu_stream_t stream) {
+  if (!img || !out || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || (flip && C < 2)) return SLU_EINVAL;
+  const size_t total = (size_t)OH * OW * C;
+  const size_t nb = (total + 255) / 256;
+  hipLaunchKernelGGL(resize_nearest_kernel, dim3((unsigned)(nb > 65535 ? 65535 : nb)), dim3(256), 0, slu_stream(stream), img, H, W, C, out, OH, OW,
+                     (double)H / (double)OH, (double)W / (double)OW, flip ? 1 : 0);
+  SLU_CHECK_LAUNCH();
+}
 
 extern "C" int slu_kitti_decode(const float* xyzi, const uint32_t* label, int N, const int32_t* lut, int lut_size, int rotate, double cos_a, double sin_a,
                                 double* pc, int32_t* bad_count, slu_stream_t stream) {

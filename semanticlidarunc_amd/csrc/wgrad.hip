@@ -556,7 +556,7 @@ int launch_wk_nchw(const WkArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" int slu_conv2d_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int H, int W, int Cout, int ksize, int dil, int pad,
-                                     float* dWp, float* dW, slu_stream_t stream) {
+                                     float* dWp, float* dW, int prezeroed, slu_stream_t stream) {
   if (!da || !src || !dWp || !dW || nsrc < 1 || nsrc > SLU_MAX_SRC || N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SLU_EINVAL;
   if (W % 16 || ((uintptr_t)da & 15) || Cout > 65535 * 32) return SLU_EUNSUPPORTED;
   WkArgs a{};
@@ -571,7 +571,7 @@ extern "C" int slu_conv2d_wgrad_nchw(const float* da, const slu_conv_src* src, i
   if (c > 65535 * 32) return SLU_EUNSUPPORTED;
   a.da = da; a.nsrc = nsrc; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.Cin = c; a.Cip = (c + 31) / 32 * 32; a.dWp = dWp;
   hipStream_t st = slu_stream(stream);
-  if (hipMemsetAsync(dWp, 0, slu_wgrad_packed_floats(Cout, c, ksize) * sizeof(float), st) != hipSuccess) return SLU_ELAUNCH;
+  if (!prezeroed && hipMemsetAsync(dWp, 0, slu_wgrad_packed_floats(Cout, c, ksize) * sizeof(float), st) != hipSuccess) return SLU_ELAUNCH;
   int rc;
   if (ksize == 3 && dil == 1 && pad == 1) rc = launch_wk_nchw<3, 1, 1>(a, st);
   else if (ksize == 3 && dil == 2 && pad == 2) rc = launch_wk_nchw<3, 2, 2>(a, st);
@@ -584,7 +584,8 @@ extern "C" int slu_conv2d_wgrad_nchw(const float* da, const slu_conv_src* src, i
   SLU_CHECK_LAUNCH();
 }
 
-extern "C" int slu_conv1x1_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int HW, int Cout, float* dW, slu_stream_t stream) {
+extern "C" int slu_conv1x1_wgrad_nchw(const float* da, const slu_conv_src* src, int nsrc, int N, int HW, int Cout, float* dW, int prezeroed,
+                                      slu_stream_t stream) {
   if (!da || !src || !dW || nsrc < 1 || nsrc > SLU_MAX_SRC || N <= 0 || HW <= 0 || Cout <= 0) return SLU_EINVAL;
   if (HW % 32 || ((uintptr_t)da & 15)) return SLU_EUNSUPPORTED;
   W1Args a{};
@@ -598,7 +599,7 @@ extern "C" int slu_conv1x1_wgrad_nchw(const float* da, const slu_conv_src* src, 
   }
   a.da = da; a.nsrc = nsrc; a.N = N; a.HW = HW; a.Cout = Cout; a.Cin = c; a.dW = dW;
   hipStream_t st = slu_stream(stream);
-  if (hipMemsetAsync(dW, 0, (size_t)Cout * c * sizeof(float), st) != hipSuccess) return SLU_ELAUNCH;
+  if (!prezeroed && hipMemsetAsync(dW, 0, (size_t)Cout * c * sizeof(float), st) != hipSuccess) return SLU_ELAUNCH;
   const int ncob = (Cout + 31) / 32, ncib = (c + 31) / 32;
   if (ncob >= 2 && ncib >= 2) return launch_w1_nchw_t<2, 2>(a, st);
   if (ncob >= 2) return launch_w1_nchw_t<2, 1>(a, st);

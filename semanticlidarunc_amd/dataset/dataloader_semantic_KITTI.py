@@ -26,9 +26,8 @@ class SemanticKitti(Dataset):
         return len(self.data_path)
 
     def projector(self, device="cuda") -> gpu_pipeline.ScanProjector:
-        if self.resize:
-            raise NotImplementedError("resize=True (cv2.resize to 128x2048, nearest) is not mirrored: project at the target size instead")
-        return gpu_pipeline.ScanProjector(id_map, self.projection, self.rotate, self.flip, device)
+        # resize=True: cv2.resize(xyzi_img, (2048, 128), INTER_NEAREST) whatever `resolution` says (the reference never reads it, :61-62)
+        return gpu_pipeline.ScanProjector(id_map, self.projection, self.rotate, self.flip, device, resize=(128, 2048) if self.resize else None)
 
     def __getitem__(self, idx):
         if torch.utils.data.get_worker_info() is not None:

@@ -56,8 +56,12 @@ class ScanProjector:
     """Main-process side: a batch of raw scans -> (range [B,1,H,W], reflectivity [B,1,H,W], xyz [B,3,H,W], normals [B,3,H,W],
     semantics int64 [B,1,H,W]) on `device`, the tuple the reference's default-collated dataset yields (dataloader :90-99)."""
 
-    def __init__(self, id_map: dict, projection=(64, 2048), rotate: bool = False, flip: bool = False, device="cuda", norm_factor: float = 0.25):
+    def __init__(self, id_map: dict, projection=(64, 2048), rotate: bool = False, flip: bool = False, device="cuda", norm_factor: float = 0.25,
+                 resize=None):
+        """resize: None, or (rows, columns) of the nearest-neighbour resize between projection and flip (SemanticKitti(resize=True) fixes it
+        to (128, 2048), dataloader_semantic_KITTI.py:61-62); the five outputs then have that size."""
         self.height, self.width = int(projection[0]), int(projection[1])
+        self.resize = None if resize is None else (int(resize[0]), int(resize[1]))
         self.rotate, self.flip, self.device, self.norm_factor = bool(rotate), bool(flip), torch.device(device), float(norm_factor)
         self._lut_cpu = id_map_lut(id_map)
         self._lut = None
@@ -70,7 +74,8 @@ class ScanProjector:
 
     @torch.no_grad()
     def __call__(self, xyzi_list, label_list, augmentation: Optional[Sequence[Tuple[Optional[float], bool]]] = None):
-        b, h, w, dev = len(xyzi_list), self.height, self.width, self.device
+        b, dev = len(xyzi_list), self.device
+        h, w = self.resize if self.resize is not None else (self.height, self.width)
         if b == 0 or b != len(label_list):
             raise RuntimeError("ScanProjector: a non-empty batch of (xyzi, label) pairs expected")
         if self._lut is None or self._lut.device != dev:
@@ -86,7 +91,11 @@ class ScanProjector:
             pts = xyzi_list[i].to(dev, non_blocking=True).contiguous()
             lab = label_list[i].to(dev, non_blocking=True).contiguous()
             pc = ops.kitti_decode(pts, lab, self._lut, bad, angle)
-            img, _ = ops.spherical_projection(pc, h, w, flip=do_flip)
+            if self.resize is None:
+                img, _ = ops.spherical_projection(pc, h, w, flip=do_flip)
+            else:       # the reference order: project, resize, flip
+                img, _ = ops.spherical_projection(pc, self.height, self.width)
+                img = ops.resize_nearest_hwc(img, h, w, flip=do_flip)
             normals = ops.build_normals(img, self.norm_factor)
             ops.range_image_split(img, normals, rng[i], refl[i], xyz[i], nrm[i], sem[i])
         if int(bad.item()):            # one sync per batch; the reference's dict lookup would have raised inside __getitem__

@@ -33,9 +33,9 @@ class LovaszFn(torch.autograd.Function):
     """Lovasz-Softmax of probabilities; d loss / d probs is produced by the forward kernels."""
 
     @staticmethod
-    def forward(ctx, probs, labels, ignore_index):
+    def forward(ctx, probs, labels, ignore_index, classes="present"):
         need = probs.requires_grad
-        loss, _, grad = ops.lovasz_fwd(probs.detach().float().contiguous(), _labels(labels, probs.device), ignore_index, need)
+        loss, _, grad = ops.lovasz_fwd(probs.detach().float().contiguous(), _labels(labels, probs.device), ignore_index, need, classes)
         ctx.save_for_backward(grad if need else torch.empty(0, device=probs.device))
         ctx.need = need
         return loss.reshape(())
@@ -43,9 +43,9 @@ class LovaszFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if not ctx.need:
-            return None, None, None
+            return None, None, None, None
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None
+        return grad * g, None, None, None
 
 
 class NllFn(torch.autograd.Function):

@@ -377,8 +377,23 @@ def softmax_nll(logits: torch.Tensor, labels: torch.Tensor, clamp: float = 1e-8,
 NLL_LOGITS, NLL_PROBS_CLAMP, NLL_PROBS_EPS, NLL_LOG_PROBS = 0, 1, 2, 3
 
 
-def lovasz_fwd(probs: torch.Tensor, labels: torch.Tensor, ignore_index=None, want_grad: bool = True):
-    """(loss f32[1], n_present f32[1], grad_probs [B,C,H,W] or None) -- Lovasz-Softmax, classes='present'."""
+def lovasz_class_mask(classes, c: int) -> int:
+    """The kernel's class set for the reference's `classes` argument (lovasz.py:66): 0 = 'present'."""
+    if classes == "present":
+        return 0
+    ids = range(c) if classes == "all" else [int(k) for k in classes]
+    mask = 0
+    for k in ids:
+        if not 0 <= k < c:
+            raise IndexError(f"Lovasz: class {k} out of range for {c} classes")      # the reference indexes probas[:, k]
+        mask |= 1 << k
+    if mask == 0:
+        raise ValueError("Lovasz: empty class list")
+    return mask
+
+
+def lovasz_fwd(probs: torch.Tensor, labels: torch.Tensor, ignore_index=None, want_grad: bool = True, classes="present"):
+    """(loss f32[1], n_summed f32[1], grad_probs [B,C,H,W] or None) -- Lovasz-Softmax over the present classes, all classes or a list."""
     _req(probs, "probs")
     _req(labels, "labels", torch.int64)
     b, c, h, w = probs.shape
@@ -393,7 +408,7 @@ def lovasz_fwd(probs: torch.Tensor, labels: torch.Tensor, ignore_index=None, wan
     npres = torch.empty(1, dtype=torch.float32, device=probs.device)
     grad = torch.empty_like(probs) if want_grad else None
     ign = INT64_MIN if ignore_index is None else int(ignore_index)
-    check(lib.slu_lovasz_fwd(probs.data_ptr(), labels.data_ptr(), b, c, h * w, ign, ws.data_ptr(), nbytes, loss.data_ptr(),
+    check(lib.slu_lovasz_fwd(probs.data_ptr(), labels.data_ptr(), b, c, h * w, ign, lovasz_class_mask(classes, c), ws.data_ptr(), nbytes, loss.data_ptr(),
                              npres.data_ptr(), _ptr(grad), _stream()), "slu_lovasz_fwd")
     return loss, npres, grad
 
@@ -496,6 +511,29 @@ class _ZeroArena:
 
 
 _ZEROS64 = _ZeroArena()
+
+
+class _ZeroArenaF32(_ZeroArena):
+    """The same for the fp32 accumulators of the weight-gradient kernels (split-K partial sums added with atomics: the packed scratch of the
+    3x3 / 2x2 families, the gradient itself for the 1x1 family): SalsaNext's ~50 of them total 7 M floats per step, one fill instead of 50.
+    Slices start on 256-byte boundaries."""
+    CHUNK = 1 << 23
+
+    def take(self, n: int, device) -> torch.Tensor:
+        n = int(n)
+        if n > self.CHUNK // 2 or torch.cuda.is_current_stream_capturing():
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        dev = torch.device(device)
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ent = self._chunks.get(key)
+        if ent is None or ent[1] + n > self.CHUNK:
+            ent = self._chunks[key] = [torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0]
+        out = ent[0][ent[1]:ent[1] + n]
+        ent[1] += (n + 63) // 64 * 64
+        return out
+
+
+_ZEROS32 = _ZeroArenaF32()
 
 
 def zeros_f64(shape, device) -> torch.Tensor:
@@ -680,9 +718,9 @@ def conv2d_wgrad_nchw(da: torch.Tensor, srcs: Sequence[ConvSource], ksize: int, 
         raise RuntimeError("conv2d_wgrad_nchw: da and the sources disagree on (N, H, W)")
     cin = sum(s.tensor.shape[1] // 4 if s.pixel_shuffle else s.tensor.shape[1] for s in srcs)
     lib = _lib.load()
-    scratch = torch.empty(lib.slu_wgrad_packed_floats(cout, cin, ksize), dtype=torch.float32, device=da.device)
+    scratch = _ZEROS32.take(lib.slu_wgrad_packed_floats(cout, cin, ksize), da.device)      # zero already: the launcher skips its fill
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=da.device)
-    check(lib.slu_conv2d_wgrad_nchw(da.data_ptr(), arr, len(srcs), n, h, w, cout, ksize, dil, pad, scratch.data_ptr(), dw.data_ptr(), _stream()),
+    check(lib.slu_conv2d_wgrad_nchw(da.data_ptr(), arr, len(srcs), n, h, w, cout, ksize, dil, pad, scratch.data_ptr(), dw.data_ptr(), 1, _stream()),
           "slu_conv2d_wgrad_nchw")
     return dw
 
@@ -699,8 +737,8 @@ def conv1x1_wgrad_nchw(da: torch.Tensor, srcs: Sequence[ConvSource]):
     arr = (_lib.ConvSrc * _lib.MAX_SRC)()
     _fill_srcs(arr, srcs)
     cin = sum(s.tensor.shape[1] for s in srcs)
-    dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=da.device)
-    check(_lib.load().slu_conv1x1_wgrad_nchw(da.data_ptr(), arr, len(srcs), n, h * w, cout, dw.data_ptr(), _stream()), "slu_conv1x1_wgrad_nchw")
+    dw = _ZEROS32.take(cout * cin, da.device).view(cout, cin, 1, 1)                         # the kernel adds its partial sums into it
+    check(_lib.load().slu_conv1x1_wgrad_nchw(da.data_ptr(), arr, len(srcs), n, h * w, cout, dw.data_ptr(), 1, _stream()), "slu_conv1x1_wgrad_nchw")
     return dw
 
 
@@ -1238,6 +1276,18 @@ def spherical_projection(pc: torch.Tensor, height: int, width: int, theta_range=
                                           1 if bins_increasing else 0, 1 if keep_farthest else 0, 1 if flip else 0, ws.data_ptr(), ws.numel(),
                                           img.data_ptr(), tr.data_ptr(), _stream()), "slu_spherical_projection_ex")
     return img, tr
+
+
+def resize_nearest_hwc(img: torch.Tensor, out_h: int, out_w: int, flip: bool = False) -> torch.Tensor:
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_NEAREST) of an [H, W, C] fp32 image [+ the dataloader's flip afterwards]."""
+    _req(img, "img")
+    if img.dim() != 3:
+        raise RuntimeError(f"resize_nearest_hwc: [H, W, C] expected, got {tuple(img.shape)}")
+    h, w, c = img.shape
+    out = torch.empty((int(out_h), int(out_w), c), dtype=torch.float32, device=img.device)
+    check(_lib.load().slu_resize_nearest_hwc(img.data_ptr(), h, w, c, out.data_ptr(), int(out_h), int(out_w), 1 if flip else 0, _stream()),
+          "slu_resize_nearest_hwc")
+    return out
 
 
 def kitti_decode(xyzi: torch.Tensor, label: torch.Tensor, lut: torch.Tensor, bad_count: torch.Tensor, rotate_deg: Optional[float] = None):

@@ -592,7 +592,10 @@ class SalsaNext(_FusedBlock):
         x = x.contiguous().float()
         if not self._inference_only():
             self._pack_training_weights()
-        if scales is None and self._inference_only() and not torch.cuda.is_current_stream_capturing():
+        # all 13 Dropout2d sites drawn (and the decoder's products composed) up front: in inference always; in training through the one-launch
+        # kernel (the per-site nn.Dropout2d path costs ~60 tiny launches per step there as well).  Not under HIP-graph capture: the Philox
+        # offset is a launch argument and would be frozen into the graph.
+        if scales is None and (self._inference_only() or _DROPOUT_KERNEL) and not torch.cuda.is_current_stream_capturing():
             scales = self._predraw_dropout(x.shape[0], x.device)
         if _CONV_PRECISION == "f16" and self._inference_only():
             x = h8.to_h8(x)             # everything downstream stays in the fp16 channel-blocked layout

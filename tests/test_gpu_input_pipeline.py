@@ -93,5 +93,21 @@ def test_dataset_mirror_and_worker_loader_yield_device_batches(cuda, tmp_path):
     _close_images(batches[0][0][0].cpu().numpy(), g["plain:range"])
     _close_images(batches[0][4][0].cpu().numpy(), g["plain:semantics"], int_exact=True)
     assert int((batches[0][0][1] > 0).sum()) < int((batches[0][0][0] > 0).sum())          # the 9000-point scan fills fewer pixels
-    with pytest.raises(NotImplementedError):
-        SemanticKitti(paths, resize=True).projector()
+    # resize=True (the reference's constructor default): always cv2.resize(..., (2048, 128), INTER_NEAREST) after the projection
+    big = SemanticKitti(paths, projection=(H, W), resize=True)[0]
+    assert big[0].shape == (1, 128, 2048) and big[2].shape == (3, 128, 2048) and big[4].shape == (1, 128, 2048)
+
+
+@pytest.mark.parametrize("size,flip", [((64, 256), False), ((48, 384), True), ((20, 100), True)])
+def test_nearest_resize_between_projection_and_flip(cuda, size, flip):
+    """SemanticKitti(resize=True), dataloader_semantic_KITTI.py:61-62 + :71-73 -- OpenCV's INTER_NEAREST restated (cv2 absent: unpinned), up- and
+    down-sampling, non-integer ratios; the flip comes AFTER the resize as in the reference."""
+    from oracle import kitti as okitti
+    g = golden("kitti_sample_16000_32x256")
+    want = okitti.sample(g["xyzi"].tobytes(), g["label"].tobytes(), id_map, (H, W), None, flip, resize=size)
+    proj = gpu_pipeline.ScanProjector(id_map, (H, W), flip=flip, device=cuda, resize=size)
+    xyzi, label = torch.from_numpy(g["xyzi"].copy()), torch.from_numpy(g["label"].view(np.int32).copy())
+    got = proj([xyzi], [label], augmentation=[(None, flip)])
+    assert got[0].shape == (1, 1, size[0], size[1])
+    for k, (a, b) in enumerate(zip(got, want)):
+        _close_images(a[0].cpu().numpy(), b, int_exact=(k == 4), max_bad=2e-2 if k == 3 else 4e-3)

@@ -53,6 +53,22 @@ def test_lovasz_known_answers_and_edge_cases(cuda):
     assert abs(float(LovaszSoftmaxStable(None)(one, torch.tensor([[[1]]], device=cuda), "probs")) - float(want)) <= 1e-6
 
 
+@pytest.mark.parametrize("tag,ign,classes", [("all_ign0", 0, "all"), ("all_none", None, "all"), ("list_ign0", 0, [1, 3, 19]), ("present_ign0", 0, "present")])
+def test_lovasz_all_classes_and_class_lists(cuda, tag, ign, classes):
+    """LovaszSoftmaxStable(classes='all' / [ids]) (lovasz.py:7,66-69): value and gradient of the reference's own class; absent classes (3, 4, 6,
+    ... never occur in these labels; 3 is in the list) contribute their largest probability."""
+    g = golden("lovasz_classes_2x20x8x64")
+    probs = torch.softmax(_t(g["logits"]), 1).to(cuda).requires_grad_(True)
+    loss = LovaszSoftmaxStable(ign, classes)(probs, _t(g["labels"]).to(cuda), "probs")
+    assert abs(float(loss) - float(g["loss_" + tag])) <= 1e-5
+    loss.backward()
+    assert float((probs.grad.cpu() - _t(g["grad_" + tag])).abs().max()) <= 1e-6
+    with pytest.raises(ValueError):
+        LovaszSoftmaxStable(0, "some")
+    with pytest.raises(IndexError):
+        LovaszSoftmaxStable(0, [1, 20])(probs.detach(), _t(g["labels"]).to(cuda), "probs")
+
+
 def test_lovasz_training_size_against_oracle(cuda):
     # BASELINE configs[1] shape: B=4, 64x2048, 20 classes, ~10 % ignored (label 0), classes 7 and 13 absent
     gen = torch.Generator().manual_seed(3)

@@ -94,6 +94,14 @@ def test_loss_golden_and_hand_derived():
     assert abs(float(olosses.nll_on_probs(_t(k["probs"]), _t(k["labels"]))) - hand_nll) < 1e-6
     # empty / all-ignored input
     assert float(olosses.lovasz_softmax(_t(k["probs"]), torch.zeros(1, 1, 4, dtype=torch.long), 0)) == 0.0
+    # classes='all' / a list of ids (lovasz.py:66-69), from the reference's own class (tools/gen_golden_r03.py lovasz_classes)
+    gc = golden("lovasz_classes_2x20x8x64")
+    for tag, ign, classes in (("all_ign0", 0, "all"), ("all_none", None, "all"), ("list_ign0", 0, [1, 3, 19]), ("present_ign0", 0, "present")):
+        p = torch.softmax(_t(gc["logits"]), 1).requires_grad_(True)
+        loss = olosses.lovasz_softmax(p, _t(gc["labels"]), ign, classes)
+        assert abs(float(loss) - float(gc["loss_" + tag])) <= 1e-6
+        loss.backward()
+        assert float((p.grad - _t(gc["grad_" + tag])).abs().max()) <= 1e-6
 
 
 def test_iou_golden():

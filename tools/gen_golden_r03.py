@@ -2,7 +2,7 @@
 """Round-3 additions to the pinned fixtures: same rules as tools/gen_golden.py (runs ONLY in the build container, imports the reference
 read-only from /root/reference, writes small data-only fixtures under tests/golden/).
 
-    python tools/gen_golden_r03.py [fpn_train] [fpn_opt_train] [effnet] [effnet_train]
+    python tools/gen_golden_r03.py [fpn_train] [fpn_opt_train] [effnet] [effnet_train] [lovasz_classes]
 
 fpn_train / fpn_opt_train: one TRAINING step of the reference's own classes (models/semanticFCN.py, baselines/Reichert/semanticFCN_opt.py) in
 train mode -- batch-statistics BatchNorm, running-statistics update, loss = sum(out * R), backward -- through the stub torchvision.models that
@@ -284,7 +284,28 @@ def gen_effnet_train():
     np.savez(os.path.join(OUT, "fpn_opt_train_efficientnet_v2_s_sd_noise.npz"), **{k: v.numpy() for k, v in noise.items()})
 
 
+def gen_lovasz_classes():
+    """LovaszSoftmaxStable(classes='all') and classes=[...] (lovasz.py:7,56-88): value and gradient of the reference's own class on inputs where
+    several classes -- one of the listed ones included -- have no valid pixel (their term is the largest probability of that class)."""
+    from losses.lovasz import LovaszSoftmaxStable as RefLovasz
+    from oracle import losses as olosses
+    g = torch.Generator().manual_seed(17)
+    logits = torch.randn(2, 20, 8, 64, generator=g) * 2.0
+    pool = torch.tensor([0, 1, 2, 5, 7, 11, 12, 19])                       # classes 3, 4, 6, ... never occur
+    labels = pool[torch.randint(0, len(pool), (2, 8, 64), generator=g)]
+    arrs = dict(logits=logits.numpy(), labels=labels.numpy())
+    for tag, ign, classes in (("all_ign0", 0, "all"), ("all_none", None, "all"), ("list_ign0", 0, [1, 3, 19]), ("present_ign0", 0, "present")):
+        p = torch.softmax(logits, 1).requires_grad_(True)
+        loss = RefLovasz(ignore_index=ign, classes=classes)(p, labels, "probs")
+        loss.backward()
+        po = torch.softmax(logits, 1)
+        assert abs(float(olosses.lovasz_softmax(po, labels, ign, classes)) - float(loss)) <= 1e-7, tag
+        arrs["loss_" + tag], arrs["grad_" + tag] = loss.detach().numpy(), p.grad.numpy()
+        print(f"  lovasz {tag}: {float(loss):.8f}")
+    save("lovasz_classes_2x20x8x64", **arrs)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["fpn_train"]
     for w in what:
-        {"fpn_train": gen_fpn_train, "fpn_opt_train": gen_fpn_opt_train, "effnet": gen_effnet, "effnet_train": gen_effnet_train}[w]()
+        {"fpn_train": gen_fpn_train, "fpn_opt_train": gen_fpn_opt_train, "effnet": gen_effnet, "effnet_train": gen_effnet_train, "lovasz_classes": gen_lovasz_classes}[w]()
