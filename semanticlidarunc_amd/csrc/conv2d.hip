@@ -19,10 +19,22 @@
 
 using namespace slu_conv;
 
+#ifdef SLU_CONV_PROF      // development aid: per-phase shader-clock totals of wave 0 of every workgroup of conv_fwd_kernel
+__device__ unsigned long long g_conv_prof[8];
+#define CONV_PROF_MARK(i)                                          \
+  {                                                                \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+    asm volatile("" ::: "memory");                                 \
+    prof_acc[i] += t_now - prof_t;                                 \
+    prof_t = t_now;                                                \
+  }
+#else
+#define CONV_PROF_MARK(i)
+#endif
+
 namespace {
 
-// GEN = false: plain sources (no PixelShuffle, no multipliers) -- every conv except UpBlock.conv1.
-// PF  = true : prefetch the next chunk's input tile into registers during the MFMA phase.
+// GEN = false: plain sources (no PixelShuffle, no multipliers) that start on chunk boundaries, W % 4 == 0 -- every conv except UpBlock.conv1.
 template <int KS, int DIL, int PAD, int CK, int MB, int WM, int WN, int RPW, bool GEN>
 __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2) ? 3 : 4)) void conv_fwd_kernel(const ConvArgs a, const float* __restrict__ resid, float* __restrict__ out) {
   constexpr int NT = 64 * WM * WN;
@@ -82,29 +94,92 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
   const int bbase = hh * PLANE + (wn * RPW) * LW + jj + (XO - PAD);
   const int abase = (wm * MB) * KSTEPS * 64 + lane;
 
-  for (int q = 0; q < a.nchunks; ++q) {
-    __syncthreads();
-    // keep the (chunk-invariant) staging address arithmetic from being hoisted out of this loop and
-    // held in registers across the MFMA phase: recompute it per chunk from an opaque copy of tid
+#ifdef SLU_CONV_PROF      // phases: barrier before staging | staged registers -> LDS (waits for the loads) | barrier | next chunk's loads issued | MFMA phase | epilogue
+  unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
+  // Software pipeline over the K-chunks: the global loads of chunk q + 1 (weight fragments + halo tile, ~10 float4 per lane) are ISSUED before the
+  // MFMA phase of chunk q and written to LDS after it, so their latency (an L2 / HBM round trip, which was a third of every wave's clocks when
+  // each chunk loaded, waited, wrote and only then multiplied) hides behind 18 000 cycles of matrix work.  One LDS buffer: the writes wait for
+  // the barrier that ends the phase reading it.
+  float4 sw[NW];
+  Item<GEN> st[NI];
+  unsigned okm = 0, psm = 0;
+  // GEN = false (plain sources whose channel ranges start on chunk boundaries, W % 4 == 0: every layer of SalsaNext but UpBlock.conv1): what a
+  // lane loads differs from chunk to chunk only by a wave-uniform base, so the per-lane part -- a 32-bit element offset per item and the
+  // validity bits -- is computed ONCE here.  Recomputing the full 64-bit index chains per chunk (to keep them out of registers across the MFMA
+  // phase) cost 25-35 % of every wave's clocks in integer multiplies (measured with -DSLU_CONV_PROF), whatever the memory did.
+  int in_off[GEN ? 1 : NI], w_off[GEN ? 1 : NW];
+  unsigned sp_ok = 0, w_ok = 0, ci_pack[GEN ? 1 : (NI + 7) / 8];
+  if constexpr (!GEN) {
+    const int plane_i = a.H * a.W;
+#pragma unroll
+    for (int k = 0; k < (NI + 7) / 8; ++k) ci_pack[k] = 0;
+    // (compile-time loops: with `#pragma unroll` these arrays were indexed dynamically and lived in scratch memory)
+    slu_static_for<NI>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      const int e = tid + i * NT;
+      const int ci = e / (LH * LW4);
+      const int rem = e - ci * (LH * LW4);
+      const int r = rem / LW4;
+      const int c4 = rem - r * LW4;
+      const int gy = y0 + r - PAD, gx4 = x0 - XO + 4 * c4;
+      const bool ok = (NIV % NT == 0 || e < NIV) && gy >= 0 && gy < a.H && gx4 >= 0 && gx4 < a.W;
+      in_off[i] = ok ? ci * plane_i + gy * a.W + gx4 : 0;
+      sp_ok |= (ok ? 1u : 0u) << i;
+      ci_pack[i / 8] |= (unsigned)(ci & 15) << (4 * (i % 8));
+    });
+    slu_static_for<NW>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      const int e = tid + i * NT;
+      const int m = e / (KSTEPS * 16);
+      const int r = e - m * (KSTEPS * 16);
+      const bool ok = (NWV % NT == 0 || e < NWV) && mblk0 + m < a.nmblk;
+      w_off[i] = ok ? m * a.nchunks * (KSTEPS * 64) + 4 * r : 0;
+      w_ok |= (ok ? 1u : 0u) << i;
+    });
+  }
+  static_assert(GEN || CK <= 16, "ci_pack holds 4 bits per item");
+  auto fetch = [&](int q) __attribute__((always_inline)) {
+    if constexpr (!GEN) {
+      const float* wq = a.wpack + ((size_t)mblk0 * a.nchunks + q) * (KSTEPS * 64);
+      slu_static_for<NW>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        sw[i] = *reinterpret_cast<const float4*>(wq + w_off[i]);
+      });
+      // the source this chunk lies in (wave-uniform: the host routes layers whose sources do not start on chunk boundaries to GEN = true)
+      const int c0 = q * CK;
+      const SrcPick sp = pick_src(a, im, c0);       // (a chain of overwrites: written as "find the index, then index" the source table went to scratch memory)
+      const float* base = sp.ptr + ((size_t)sp.ns * sp.C + sp.cl) * ((size_t)a.H * a.W);
+      const int lim = a.Cin - c0;                 // channels of this chunk that exist (the last chunk of the last source may be short)
+      okm = 0;
+      slu_static_for<NI>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        const int ci = (int)((ci_pack[i / 8] >> (4 * (i % 8))) & 15u);
+        const bool ok = ((sp_ok >> i) & 1u) && ci < lim;
+        st[i].v = *reinterpret_cast<const float4*>(base + (ok ? in_off[i] : 0));
+        okm |= (ok ? 1u : 0u) << i;
+      });
+      return;
+    }
+    // keep the (chunk-invariant) staging address arithmetic from being hoisted out of the chunk loop and held in registers across the MFMA
+    // phase: recompute it per chunk from an opaque copy of tid
     int tq = tid;
     asm volatile("" : "+v"(tq));
-    // ---- A fragments of this chunk (L2-resident, MBLK contiguous runs of KSTEPS*64 floats) ----
-    float4 sw[NW];
+    // ---- A fragments of the chunk (L2-resident, MBLK contiguous runs of KSTEPS*64 floats) ----
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const int e = tq + i * NT;
       int m = e / (KSTEPS * 16);
       const int r = e - m * (KSTEPS * 16);
       const bool ok = (NWV % NT == 0 || e < NWV) && mblk0 + m < a.nmblk;
+      // out-of-range fragments read the packed weights' first record (always mapped) and are zeroed when they are written to LDS
       const size_t off = ok ? ((size_t)(mblk0 + m) * a.nchunks + q) * (KSTEPS * 64) + 4 * r : 0;
       sw[i] = *reinterpret_cast<const float4*>(a.wpack + off);
-      if (!ok) sw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // ---- halo tile of CK input channels (zero outside the image / beyond Cin): all loads of a thread are
-    //      issued back to back (branch-free: clamped address + select), then written to LDS ----
+    // ---- halo tile of CK input channels (zero outside the image / beyond Cin): all loads of a thread are issued back to back
+    //      (branch-free: clamped address, the select happens at the LDS write) ----
+    okm = psm = 0;
     if (a.vec) {
-      Item<GEN> st[NI];
-      unsigned okm = 0, psm = 0;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int e = tq + i * NT;
@@ -119,13 +194,19 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         okm |= (ok ? 1u : 0u) << i;
         psm |= (ps ? 1u : 0u) << i;
       }
+    }
+  };
+  auto commit = [&](int q) __attribute__((always_inline)) {
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+    if (!GEN || a.vec) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int e = tq + i * NT;
         if (NIV % NT == 0 || e < NIV)
           reinterpret_cast<float4*>(s_in)[e] = item_value<GEN>(st[i], (okm >> i) & 1u, (psm >> i) & 1u);
       }
-    } else {
+    } else {      // W % 4 != 0 (no layer of the models): element by element, not pipelined
       for (int e = tq; e < CK * PLANE; e += NT) {
         const int ci = e / PLANE;
         const int rem = e - ci * PLANE;
@@ -140,9 +221,26 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const int e = tq + i * NT;
-      if (NWV % NT == 0 || e < NWV) reinterpret_cast<float4*>(s_w)[e] = sw[i];
+      bool ok;
+      if constexpr (GEN) ok = (NWV % NT == 0 || e < NWV) && mblk0 + e / (KSTEPS * 16) < a.nmblk;
+      else ok = (w_ok >> i) & 1u;
+      if (NWV % NT == 0 || e < NWV) reinterpret_cast<float4*>(s_w)[e] = ok ? sw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+
+  fetch(0);
+  for (int q = 0; q < a.nchunks; ++q) {
+    __syncthreads();                       // every wave has finished reading chunk q - 1 from LDS
+    CONV_PROF_MARK(0)
+    commit(q);
+#ifdef SLU_CONV_PROF
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    CONV_PROF_MARK(1)
     __syncthreads();
+    CONV_PROF_MARK(2)
+    if (q + 1 < a.nchunks) fetch(q + 1);   // in flight during the MFMA phase below
+    CONV_PROF_MARK(3)
     // ---- K-steps: the MB + NB operand reads of step s + 1 are issued before the MB * NB MFMAs of step s, in THIS order (sched_barrier pins
     //      it; left alone the compiler emits read, wait, MFMA, read, wait, ... and every 64-cycle MFMA starts with an LDS round trip) ----
     float av[2][MB], bv[2][NB];
@@ -165,6 +263,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
         for (int i = 0; i < MB; ++i) acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][b], acc[i][b], 0, 0, 0);
       if (_PIN) __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef SLU_CONV_PROF
+    asm volatile("s_nop 0" ::"v"(acc[MB - 1][NB - 1][0]));      // the last MFMA has retired
+#endif
+    CONV_PROF_MARK(4)
   }
 
   // ---- epilogue: bias, LeakyReLU, folded BatchNorm, residual, store (2 x 128 B per instruction).
@@ -181,6 +283,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
   // The accumulator indices must be COMPILE-TIME constants: with a plain `#pragma unroll` over i the body (NB x 16 stores + the statistics
   // butterfly) was too large for the unroller in the MB = 2, NB = 4 instantiations ("loop not unrolled"), acc[i][b] became a dynamic index and
   // the whole accumulator array lived in scratch memory -- 360 scratch loads / stores around the 288 MFMAs of the K loop of the largest tiles.
+  // The rare wave-uniform options (tanh / SiLU, activation after the residual) take a generic per-element form; the common one -- bias ->
+  // LeakyReLU -> folded BatchNorm [-> + residual] -- is a tight loop with the residual loads of an accumulator tile issued 8 at a time: as
+  // per-element branches the options cost ~60 instructions and, with a residual, one load + s_waitcnt vmcnt(0) per stored element (128 memory
+  // round trips per lane in a row).
+  const bool special = act_tanh || act_silu || slope_post != 1.0f;
   slu_static_for<MB>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     const int ml = wm * MB + i;               // channel block inside the workgroup tile
@@ -191,21 +298,51 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
       constexpr int b = decltype(bc)::value;
       const int gy = y0 + wn * RPW + (b >> 1), gx = x0 + (b & 1) * 32 + jj;
       const bool pix_ok = gy < a.H && gx < a.W;
+      const size_t pix = (size_t)gy * a.W + gx;
+      if (special) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int co = mblk0 * 32 + cl;
-        const bool ok = pix_ok && co < a.Cout;
-        const size_t o = ok ? ((size_t)n * a.Cout + co) * plane + (size_t)gy * a.W + gx : 0;
-        float v = acc[i][b][r] + s_epi[cl];
-        v = v > 0.0f ? v : v * slope_pre;
-        if (act_tanh) v = tanhf(v);
-        if (act_silu) v = v / (1.0f + expf(-v));      // nn.SiLU (EfficientNetV2 blocks)
-        v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
-        if (resid) v += resid[o];
-        v = v > 0.0f ? v : v * slope_post;
-        if (ok) out[o] = v;
-        if (want_stats && ok) { ssum[r] += v; ssq[r] += v * v; }
+        for (int r = 0; r < 16; ++r) {
+          const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const int co = mblk0 * 32 + cl;
+          const bool ok = pix_ok && co < a.Cout;
+          const size_t o = ok ? ((size_t)n * a.Cout + co) * plane + pix : 0;
+          float v = acc[i][b][r] + s_epi[cl];
+          v = v > 0.0f ? v : v * slope_pre;
+          if (act_tanh) v = tanhf(v);
+          if (act_silu) v = v / (1.0f + expf(-v));      // nn.SiLU (EfficientNetV2 blocks)
+          v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
+          if (resid) v += resid[o];
+          v = v > 0.0f ? v : v * slope_post;
+          if (ok) out[o] = v;
+          if (want_stats && ok) { ssum[r] += v; ssq[r] += v * v; }
+        }
+      } else {
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+          float rv[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) rv[k] = 0.0f;
+          if (resid) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int r = 8 * h8 + k;
+              const int co = mblk0 * 32 + ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              rv[k] = resid[(pix_ok && co < a.Cout) ? ((size_t)n * a.Cout + co) * plane + pix : 0];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int r = 8 * h8 + k;
+            const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int co = mblk0 * 32 + cl;
+            const bool ok = pix_ok && co < a.Cout;
+            float v = acc[i][b][r] + s_epi[cl];
+            v = v > 0.0f ? v : v * slope_pre;
+            v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl] + rv[k];
+            if (ok) out[((size_t)n * a.Cout + co) * plane + pix] = v;
+            if (want_stats && ok) { ssum[r] += v; ssq[r] += v * v; }
+          }
+        }
       }
     });
     if (want_stats) {
@@ -234,6 +371,14 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
       }
     }
   }
+#ifdef SLU_CONV_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CONV_PROF_MARK(5)
+  if (tid == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_prof[i], prof_acc[i]);
+    atomicAdd(&g_conv_prof[6], 1ull);
+  }
+#endif
 }
 
 __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int ks, int ck, int nchunks,
@@ -344,6 +489,14 @@ extern "C" int slu_pack_conv_weights_multi(const slu_pack_job* jobs_dev, int njo
   hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(blocks), dim3(256), 0, slu_stream(stream), jobs_dev, njobs, total);
   SLU_CHECK_LAUNCH();
 }
+
+#ifdef SLU_CONV_PROF
+extern "C" int slu_conv_prof_read(unsigned long long* out8) {      // copies and clears the phase clocks (synchronises the device)
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_prof), sizeof(g_conv_prof)) != hipSuccess) return SLU_ELAUNCH;
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof), z, sizeof(z)) == hipSuccess ? SLU_OK : SLU_ELAUNCH;
+}
+#endif
 
 int slu_conv2d_fwd_f16x3_impl(const slu_conv_desc* d, hipStream_t st);   // conv2d_f16x3.hip
 

@@ -45,7 +45,8 @@ struct ConvArgs {
   float slope;
   int has_act;
   int vec;  // W % 4 == 0 and every base pointer 16-byte aligned: float4 staging path
-  int gen;  // some source is read through PixelShuffle or carries a multiplier
+  int gen;  // some source is read through PixelShuffle or carries a multiplier -- or the layer does not fit the plain kernels' fast addressing
+            // (float4 path, every source starting on a K-chunk boundary, 31-bit element offsets inside one chunk of one image)
   double* stats;  // nullable: [2][Cout] per-channel sum / sum of squares of the stored output, accumulated (train-mode BatchNorm)
 };
 
@@ -207,7 +208,9 @@ inline int fill_args(const slu_conv_desc* d, ConvArgs& a) {
   for (int s = 0; s < d->nsrc; ++s) {
     if (reinterpret_cast<uintptr_t>(d->src[s].ptr) & 15) a.vec = 0;
     if (d->src[s].pixel_shuffle || d->src[s].scale) a.gen = 1;
+    if (a.src[s].cbeg % d->ck) a.gen = 1;
   }
+  if (!a.vec || (long long)(d->ck + 1) * d->H * d->W >= 0x7fffffffLL || (long long)a.nmblk * a.nchunks * 64 * 9 * 8 >= 0x7fffffffLL) a.gen = 1;
   return SLU_OK;
 }
 
