@@ -15,6 +15,8 @@
 // Work decomposition: a workgroup owns TH rows x 64 columns of one image and WM*MB*32 output
 // channels; per K-chunk (CK input channels) it stages the (TH+2*pad) x (64+2*pad) halo tile of
 // each channel and the matching weight fragments into LDS, then every wave runs KS*KS*CK/2 K-steps.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 using namespace slu_conv;
@@ -269,98 +271,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MB * RPW >= 4) ? 2 : ((MB * RPW >= 2
     CONV_PROF_MARK(4)
   }
 
-  // ---- epilogue: bias, LeakyReLU, folded BatchNorm, residual, store (2 x 128 B per instruction).
-  //      Per-channel constants come from LDS; `resid` / `out` are __restrict__ kernel arguments (the ABI
-  //      forbids out aliasing an input), so residual loads are scheduled ahead of the stores instead of
-  //      each waiting behind the previous store. ----
-  const size_t plane = (size_t)a.H * a.W;
-  // activation as two leaky slopes (1.0 = identity): before BatchNorm/residual, or (has_act & 4) after them
-  const int act_kind = a.has_act & 3;
-  const bool act_late = (a.has_act & 4) != 0, act_tanh = act_kind == 2, act_silu = act_kind == 3;
-  const float slope_pre = (act_kind == 1 && !act_late) ? a.slope : 1.0f;
-  const float slope_post = (act_kind == 1 && act_late) ? a.slope : 1.0f;
+  // ---- epilogue: bias, LeakyReLU, folded BatchNorm, residual, store (conv_common.h) ----
   const bool want_stats = a.stats != nullptr;      // wave-uniform
-  // The accumulator indices must be COMPILE-TIME constants: with a plain `#pragma unroll` over i the body (NB x 16 stores + the statistics
-  // butterfly) was too large for the unroller in the MB = 2, NB = 4 instantiations ("loop not unrolled"), acc[i][b] became a dynamic index and
-  // the whole accumulator array lived in scratch memory -- 360 scratch loads / stores around the 288 MFMAs of the K loop of the largest tiles.
-  // The rare wave-uniform options (tanh / SiLU, activation after the residual) take a generic per-element form; the common one -- bias ->
-  // LeakyReLU -> folded BatchNorm [-> + residual] -- is a tight loop with the residual loads of an accumulator tile issued 8 at a time: as
-  // per-element branches the options cost ~60 instructions and, with a residual, one load + s_waitcnt vmcnt(0) per stored element (128 memory
-  // round trips per lane in a row).
-  const bool special = act_tanh || act_silu || slope_post != 1.0f;
-  slu_static_for<MB>([&](auto ic) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value;
-    const int ml = wm * MB + i;               // channel block inside the workgroup tile
-    float ssum[16], ssq[16];                  // this lane's share of the batch statistics (its NB pixels of 16 channels)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.0f;
-    slu_static_for<NB>([&](auto bc) __attribute__((always_inline)) {
-      constexpr int b = decltype(bc)::value;
-      const int gy = y0 + wn * RPW + (b >> 1), gx = x0 + (b & 1) * 32 + jj;
-      const bool pix_ok = gy < a.H && gx < a.W;
-      const size_t pix = (size_t)gy * a.W + gx;
-      if (special) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const int co = mblk0 * 32 + cl;
-          const bool ok = pix_ok && co < a.Cout;
-          const size_t o = ok ? ((size_t)n * a.Cout + co) * plane + pix : 0;
-          float v = acc[i][b][r] + s_epi[cl];
-          v = v > 0.0f ? v : v * slope_pre;
-          if (act_tanh) v = tanhf(v);
-          if (act_silu) v = v / (1.0f + expf(-v));      // nn.SiLU (EfficientNetV2 blocks)
-          v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
-          if (resid) v += resid[o];
-          v = v > 0.0f ? v : v * slope_post;
-          if (ok) out[o] = v;
-          if (want_stats && ok) { ssum[r] += v; ssq[r] += v * v; }
-        }
-      } else {
-#pragma unroll
-        for (int h8 = 0; h8 < 2; ++h8) {
-          float rv[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) rv[k] = 0.0f;
-          if (resid) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const int r = 8 * h8 + k;
-              const int co = mblk0 * 32 + ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-              rv[k] = resid[(pix_ok && co < a.Cout) ? ((size_t)n * a.Cout + co) * plane + pix : 0];
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int r = 8 * h8 + k;
-            const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const int co = mblk0 * 32 + cl;
-            const bool ok = pix_ok && co < a.Cout;
-            float v = acc[i][b][r] + s_epi[cl];
-            v = v > 0.0f ? v : v * slope_pre;
-            v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl] + rv[k];
-            if (ok) out[((size_t)n * a.Cout + co) * plane + pix] = v;
-            if (want_stats && ok) { ssum[r] += v; ssq[r] += v * v; }
-          }
-        }
-      }
-    });
-    if (want_stats) {
-      // the 32 lanes of a half hold 32 pixels of the same 16 channels: butterfly over them, lane 0 of each half adds the tile's share
-      // to the workgroup's LDS accumulators (float), which go out as one double atomic per channel at the end
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s1 = ssum[r], s2 = ssq[r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        if (jj == 0) {
-          const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          atomicAdd(&s_stat[cl], (double)s1);
-          atomicAdd(&s_stat[MBLK * 32 + cl], (double)s2);
-        }
-      }
-    }
-  });
+  conv_epilogue<MB, NB, MBLK, RPW>(a, acc, s_epi, s_stat, resid, out, n, y0, x0, mblk0, wm, wn, hh, jj);
   if (want_stats) {
     __syncthreads();
     if (tid < MBLK * 32) {

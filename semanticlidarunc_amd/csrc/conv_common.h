@@ -148,6 +148,112 @@ __device__ __forceinline__ float4 item_value(const Item<GEN>& it, bool ok, bool 
   return ok ? r : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+
+// Epilogue of the fp32 conv kernel (conv2d.hip): the accumulators of one wave (MB channel blocks x NB pixel blocks of the
+// workgroup's tile at (n, y0, x0), channel blocks from mblk0 + wm * MB) -> bias, activation, folded BatchNorm, residual, store, batch statistics
+// into the workgroup's LDS accumulators s_stat (flushed to a.stats by the caller after a barrier).
+template <int MB, int NB, int MBLK, int RPW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MB][NB], const float* s_epi, double* s_stat, const float* __restrict__ resid,
+                                              float* __restrict__ out, int n, int y0, int x0, int mblk0, int wm, int wn, int hh, int jj) {
+  // ---- epilogue: bias, LeakyReLU, folded BatchNorm, residual, store (2 x 128 B per instruction).
+  //      Per-channel constants come from LDS; `resid` / `out` are __restrict__ kernel arguments (the ABI
+  //      forbids out aliasing an input), so residual loads are scheduled ahead of the stores instead of
+  //      each waiting behind the previous store. ----
+  const size_t plane = (size_t)a.H * a.W;
+  // activation as two leaky slopes (1.0 = identity): before BatchNorm/residual, or (has_act & 4) after them
+  const int act_kind = a.has_act & 3;
+  const bool act_late = (a.has_act & 4) != 0, act_tanh = act_kind == 2, act_silu = act_kind == 3;
+  const float slope_pre = (act_kind == 1 && !act_late) ? a.slope : 1.0f;
+  const float slope_post = (act_kind == 1 && act_late) ? a.slope : 1.0f;
+  const bool want_stats = a.stats != nullptr;      // wave-uniform
+  // The accumulator indices must be COMPILE-TIME constants: with a plain `#pragma unroll` over i the body (NB x 16 stores + the statistics
+  // butterfly) was too large for the unroller in the MB = 2, NB = 4 instantiations ("loop not unrolled"), acc[i][b] became a dynamic index and
+  // the whole accumulator array lived in scratch memory -- 360 scratch loads / stores around the 288 MFMAs of the K loop of the largest tiles.
+  // The rare wave-uniform options (tanh / SiLU, activation after the residual) take a generic per-element form; the common one -- bias ->
+  // LeakyReLU -> folded BatchNorm [-> + residual] -- is a tight loop with the residual loads of an accumulator tile issued 8 at a time: as
+  // per-element branches the options cost ~60 instructions and, with a residual, one load + s_waitcnt vmcnt(0) per stored element (128 memory
+  // round trips per lane in a row).
+  const bool special = act_tanh || act_silu || slope_post != 1.0f;
+  slu_static_for<MB>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const int ml = wm * MB + i;               // channel block inside the workgroup tile
+    float ssum[16], ssq[16];                  // this lane's share of the batch statistics (its NB pixels of 16 channels)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.0f;
+    slu_static_for<NB>([&](auto bc) __attribute__((always_inline)) {
+      constexpr int b = decltype(bc)::value;
+      const int gy = y0 + wn * RPW + (b >> 1), gx = x0 + (b & 1) * 32 + jj;
+      const bool pix_ok = gy < a.H && gx < a.W;
+      const size_t pix = (size_t)gy * a.W + gx;
+      if (special) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const int co = mblk0 * 32 + cl;
+          const bool ok = pix_ok && co < a.Cout;
+          const size_t o = ok ? ((size_t)n * a.Cout + co) * plane + pix : 0;
+          float v = acc[i][b][r] + s_epi[cl];
+          v = v > 0.0f ? v : v * slope_pre;
+          if (act_tanh) v = tanhf(v);
+          if (act_silu) v = v / (1.0f + expf(-v));      // nn.SiLU (EfficientNetV2 blocks)
+          v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl];
+          if (resid) v += resid[o];
+          v = v > 0.0f ? v : v * slope_post;
+          if (ok) out[o] = v;
+          if (want_stats && ok) { ssum[r] += v; ssq[r] += v * v; }
+        }
+      } else {
+        // vmcnt counts loads AND stores in issue order: a wait for a residual load placed between two stores also waits for every older store
+        // to be acknowledged (measured: the stores of a tile then went out ~8 per memory round trip, a third of the kernel on the 32-channel
+        // full-resolution layers).  So: all residual loads of the tile, then all arithmetic (results back into the accumulator registers), then
+        // all stores with no wait between them.
+        float rv[16];
+        if (resid) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = mblk0 * 32 + ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            rv[r] = resid[(pix_ok && co < a.Cout) ? ((size_t)n * a.Cout + co) * plane + pix : 0];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const bool ok = pix_ok && mblk0 * 32 + cl < a.Cout;
+          float v = acc[i][b][r] + s_epi[cl];
+          v = v > 0.0f ? v : v * slope_pre;
+          v = v * s_epi[MBLK * 32 + cl] + s_epi[2 * MBLK * 32 + cl] + rv[r];
+          acc[i][b][r] = v;
+          if (want_stats && ok) { ssum[r] += v; ssq[r] += v * v; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = mblk0 * 32 + ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (pix_ok && co < a.Cout) out[((size_t)n * a.Cout + co) * plane + pix] = acc[i][b][r];
+        }
+      }
+    });
+    if (want_stats) {
+      // the 32 lanes of a half hold 32 pixels of the same 16 channels: butterfly over them, lane 0 of each half adds the tile's share
+      // to the workgroup's LDS accumulators (float), which go out as one double atomic per channel at the end
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s1 = ssum[r], s2 = ssq[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (jj == 0) {
+          const int cl = ml * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          atomicAdd(&s_stat[cl], (double)s1);
+          atomicAdd(&s_stat[MBLK * 32 + cl], (double)s2);
+        }
+      }
+    }
+  });
+}
+
 enum TileCfg { M32_TH8 = 0, M64_TH8, M128_TH4, M32_TH4, M64_TH4 };
 
 inline long long wg_count(const ConvArgs& a, int th, int mblk) {
