@@ -19,4 +19,10 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 cp "$(find "$OUT/tstats" -name '*kernel_stats.csv' | head -1)" "$OUT/train_kernel_stats.csv"
 rm -rf "$OUT/tstats"
 timeout -k 10 300 python tools/wgrad_bench.py > "$OUT/train_wgrad_per_shape.txt" 2>&1
+echo "[7] socket power / sclk while the two benches run (rocm-smi every 0.25 s)"
+bash tools/power_trace.sh "$OUT/power_trace_bench.txt" timeout -k 10 300 python bench.py --no-cpu-baseline --no-train-step --no-shared-prefix --steps 200 --warmup 3 > "$OUT/power_trace_bench_line.json" 2> /dev/null
+bash tools/power_trace.sh "$OUT/power_trace_train.txt" timeout -k 10 300 python tools/train_bench.py --batch 4 --steps 150 --warmup 3 > "$OUT/power_trace_train_line.json" 2> /dev/null
+echo "[8] batch-size sweep of the inference step; fp32 conv kernel phase clocks (needs ab_libs/libslu_convprof.so)"
+for s in 1 2 4 16; do timeout -k 10 200 python bench.py --scans $s --no-cpu-baseline --no-train-step --no-shared-prefix 2> /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print($s, 'scans/step:', d['value'], 'scans/s', d['ms_per_step'], 'ms/step')"; done > "$OUT/bench_f16_batch_sweep.txt"
+if [ -f ab_libs/libslu_convprof.so ]; then timeout -k 10 300 python tools/conv_phase_prof.py ab_libs/libslu_convprof.so 4 > "$OUT/train_conv_phase_clocks.txt" 2>&1; fi
 echo done
