@@ -149,8 +149,11 @@ class ConvLayerFn(torch.autograd.Function):
             for i, (shape, s, ps) in enumerate(zip(ctx.src_shapes, cfg.scales, cfg.shuffles)):
                 contributed = shape[1] // 4 if ps else shape[1]
                 if need[6 + i]:
-                    if nsrc == 1 and not ps and s is None:
-                        dsrc[i] = dcat
+                    if not ps and s is None:
+                        # a plain source's gradient is a channel slice of dcat: handed out as a VIEW.  Where the tensor has a second consumer
+                        # (a1 / a2 of every block feed the next conv AND the concat) the engine's accumulation reads the strided slice directly
+                        # and the copy `split_grad` made is gone; a sole consumer's node makes it contiguous on entry, which costs what the copy did
+                        dsrc[i] = dcat if nsrc == 1 else dcat.narrow(1, cbeg, contributed)
                     else:
                         dsrc[i] = ops.split_grad(dcat, cbeg, shape, ps, s)
                 cbeg += contributed
