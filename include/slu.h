@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SLU_ABI_VERSION 30
+#define SLU_ABI_VERSION 31
 
 #define SLU_OK            0
 #define SLU_EINVAL       -1   /* null pointer / non-positive size / inconsistent descriptor   */
@@ -226,6 +226,18 @@ int slu_affine_fwd(const float* y, const float* a, const float* b, const float* 
 /* da = (k1[c]*dz + k2[c] + k3[c]*y) * (has_act && y <= 0 ? slope : 1);  dbias[c] += sum da  (k*, y, dbias nullable) */
 int slu_act_affine_bwd(const float* dz, const float* y, const float* k1, const float* k2, const float* k3, float slope,
                        int has_act, int N, int C, int HW, float* da, double* dbias, slu_stream_t stream);
+/* The two BatchNorm passes of a layer with their coefficient launches folded in (a training step has 42 such layers):
+ * slu_bn_apply_fwd = slu_bn_coeffs_fwd + slu_affine_fwd: z = gamma (y - mean) invstd + beta [+ resid]; mean / invstd [C] are written for the
+ *   backward, the running statistics updated as slu_bn_coeffs_fwd does.
+ * slu_bn_act_bwd = slu_bn_coeffs_bwd + slu_act_affine_bwd + the fp64 -> fp32 rounding of the bias gradient: has_bn = 0: k1 = 1, k2 = k3 = 0.
+ *   acc64 [C] fp64 and ticket [C] uint32 are caller-ZEROED scratch (the last workgroup of a channel to add its partial sum writes dbias[c]);
+ *   dbias nullable (then acc64 / ticket are unused); dgamma / dbeta [C] fp32 (has_bn only). */
+int slu_bn_apply_fwd(const float* y, const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float eps,
+                     float momentum, int train, float* running_mean, float* running_var, const float* resid, float* z, int N, int C, int HW,
+                     float* mean, float* invstd, slu_stream_t stream);
+int slu_bn_act_bwd(const float* dz, const float* y, const double* s1, const double* s2, double count, const float* gamma, const float* mean,
+                   const float* invstd, int has_bn, int train, float slope, int has_act, int N, int C, int HW, float* da, double* acc64,
+                   unsigned* ticket, float* dbias, float* dgamma, float* dbeta, slu_stream_t stream);
 /* src [N,C,HW] -> dst [N,HW,Cp], Cp = C rounded up to 32, padding channels zero */
 int slu_nchw_to_nhwc(const float* src, int N, int C, int HW, float* dst, slu_stream_t stream);
 /* the conv input described by `src` (concat / PixelShuffle / multipliers applied) as [N,H*W,Cp] */

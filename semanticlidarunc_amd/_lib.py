@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 MAX_SRC = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslu_hip.so")
@@ -130,6 +130,10 @@ SIGNATURES = {
     "slu_bn_coeffs_bwd": (C.c_int, [c_f64p, c_f64p, C.c_double, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
                                     c_f32p, c_f32p, c_stream]),
     "slu_affine_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "slu_bn_apply_fwd": (C.c_int, [c_f32p, c_f64p, c_f64p, C.c_double, c_f32p, c_f32p, C.c_float, C.c_float, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
+                                   C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_stream]),
+    "slu_bn_act_bwd": (C.c_int, [c_f32p, c_f32p, c_f64p, c_f64p, C.c_double, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, c_f32p, c_f64p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_stream]),
     "slu_act_affine_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                      c_f32p, c_f64p, c_stream]),
     "slu_nchw_to_nhwc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),

@@ -67,6 +67,11 @@ def nbt_scope_exit() -> None:
             torch._foreach_add_(pend, 1)
 
 
+# A/B switches: 0 = the BatchNorm coefficient launches + separate apply passes (+ the fp64 -> fp32 bias-gradient conversion) of round 2
+_BN_FUSED_FWD = os.environ.get("SLU_BN_FUSED_FWD", "1") != "0"
+_BN_FUSED_BWD = os.environ.get("SLU_BN_FUSED_BWD", "1") != "0"
+
+
 class ConvLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: LayerCfg, weight, bias, gamma, beta, resid, *tensors):
@@ -86,12 +91,16 @@ class ConvLayerFn(torch.autograd.Function):
             track = train_stats and bn.track_running_stats and bn.running_mean is not None
             if track:
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-            mean, invstd, a, b = ops.bn_coeffs_fwd(sums, m, gamma.detach(), beta.detach(), bn.eps, mom,
-                                                   bn.running_mean if (track or not train_stats) else None,
-                                                   bn.running_var if (track or not train_stats) else None, train_stats)
+            rm = bn.running_mean if (track or not train_stats) else None
+            rv = bn.running_var if (track or not train_stats) else None
+            rs = None if resid is None else resid.detach().contiguous()
+            if _BN_FUSED_FWD:
+                z, mean, invstd = ops.bn_apply_fwd(y, sums, m, gamma.detach(), beta.detach(), bn.eps, mom, rm, rv, train_stats, rs)
+            else:
+                mean, invstd, a, b = ops.bn_coeffs_fwd(sums, m, gamma.detach(), beta.detach(), bn.eps, mom, rm, rv, train_stats)
+                z = ops.affine(y, a, b, rs)
             if track:
                 bump_num_batches_tracked(bn)
-            z = ops.affine(y, a, b, None if resid is None else resid.detach().contiguous())
         elif resid is not None:
             z = ops.affine(y, None, None, resid.detach().contiguous())
         else:
@@ -117,15 +126,25 @@ class ConvLayerFn(torch.autograd.Function):
         need = ctx.needs_input_grad                      # (cfg, weight, bias, gamma, beta, resid, *tensors)
         d_resid = dz if (ctx.has_resid and need[5]) else None
         dgamma = dbeta = None
-        k1 = k2 = k3 = None
-        if ctx.has_bn:
+        if not _BN_FUSED_BWD:
+            k1 = k2 = k3 = None
+            if ctx.has_bn:
+                gamma, mean, invstd = saved[2 + nsrc:5 + nsrc]
+                s1, s2 = ops.bn_bwd_reduce(dz, y, mean, invstd)
+                k1, k2, k3, dgamma, dbeta = ops.bn_coeffs_bwd(s1, s2, float(n * h * w), gamma.detach(), mean, invstd, ctx.train_stats)
+                if not ctx.train_stats:
+                    k2 = k3 = None
+            da, db = ops.act_affine_bwd(dz, y if (cfg.slope is not None or k3 is not None) else None, k1, k2, k3, cfg.slope, ctx.has_bias)
+            dbias = db.float() if ctx.has_bias else None
+        elif ctx.has_bn:
             gamma, mean, invstd = saved[2 + nsrc:5 + nsrc]
             s1, s2 = ops.bn_bwd_reduce(dz, y, mean, invstd)
-            k1, k2, k3, dgamma, dbeta = ops.bn_coeffs_bwd(s1, s2, float(n * h * w), gamma.detach(), mean, invstd, ctx.train_stats)
-            if not ctx.train_stats:
-                k2 = k3 = None
-        da, db = ops.act_affine_bwd(dz, y if (cfg.slope is not None or k3 is not None) else None, k1, k2, k3, cfg.slope, ctx.has_bias)
-        dbias = db.float() if (ctx.has_bias and need[2]) else None
+            da, dbias, dgamma, dbeta = ops.bn_act_bwd(dz, y, s1, s2, float(n * h * w), gamma.detach(), mean, invstd, ctx.train_stats, cfg.slope,
+                                                      ctx.has_bias)
+        else:
+            da, dbias, _, _ = ops.bn_act_bwd(dz, y if cfg.slope is not None else None, slope=cfg.slope, want_dbias=ctx.has_bias)
+        if not need[2]:
+            dbias = None
         srcs = [ConvSource(t.contiguous(), s, ps) for t, s, ps in zip(tensors, cfg.scales, cfg.shuffles)]
         cin = weight.shape[1]
         dweight = None

@@ -615,6 +615,53 @@ def affine(y, a=None, b=None, resid=None):
     return z
 
 
+def bn_apply_fwd(y, sums, count: float, gamma, beta, eps: float, momentum: float, running_mean, running_var, train: bool, resid=None):
+    """(z, mean, invstd): BatchNorm2d on y [+ resid] in ONE launch (coefficients derived inside; running statistics updated in train mode)."""
+    _req(y, "y")
+    n, c, h, w = y.shape
+    for t, nme in ((gamma, "gamma"), (beta, "beta")):
+        _req(t, nme)
+    if resid is not None:
+        _req(resid, "resid")
+        if resid.shape != y.shape:
+            raise RuntimeError("resid shape mismatch")
+    if running_mean is not None:
+        _req(running_mean, "running_mean")
+        _req(running_var, "running_var")
+    s, q = (sums if sums is not None else (None, None))
+    z = torch.empty_like(y)
+    mi = torch.empty((2, c), dtype=torch.float32, device=y.device)
+    check(_lib.load().slu_bn_apply_fwd(y.data_ptr(), _ptr(s), _ptr(q), float(count), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
+                                       1 if train else 0, _ptr(running_mean), _ptr(running_var), _ptr(resid), z.data_ptr(), n, c, h * w,
+                                       mi[0].data_ptr(), mi[1].data_ptr(), _stream()), "slu_bn_apply_fwd")
+    if train and running_mean is not None:
+        torch.autograd.graph.increment_version(running_mean)      # written through raw pointers (see bn_coeffs_fwd)
+        torch.autograd.graph.increment_version(running_var)
+    return z, mi[0], mi[1]
+
+
+def bn_act_bwd(dz, y, s1=None, s2=None, count: float = 1.0, gamma=None, mean=None, invstd=None, train: bool = False, slope=None,
+               want_dbias: bool = True):
+    """(da, dbias f32 or None, dgamma, dbeta): the BatchNorm + LeakyReLU backward of a conv layer in ONE launch from the reduction sums s1 / s2
+    (None: no BatchNorm), the bias gradient rounded to fp32 inside."""
+    _req(dz, "dz")
+    n, c, h, w = dz.shape
+    has_bn = s1 is not None
+    if y is not None:
+        _req(y, "y")
+        if y.shape != dz.shape:
+            raise RuntimeError("y shape mismatch")
+    da = torch.empty_like(dz)
+    out = torch.empty((3, c), dtype=torch.float32, device=dz.device)            # dbias | dgamma | dbeta
+    scratch = zeros_f64((2, c), dz.device) if want_dbias else None          # row 0: fp64 sums, row 1: the channels' ticket counters (uint32)
+    check(_lib.load().slu_bn_act_bwd(dz.data_ptr(), _ptr(y), _ptr(s1), _ptr(s2), float(count), _ptr(gamma), _ptr(mean), _ptr(invstd),
+                                     1 if has_bn else 0, 1 if train else 0, 0.0 if slope is None else float(slope), 0 if slope is None else 1,
+                                     n, c, h * w, da.data_ptr(), None if scratch is None else scratch[0].data_ptr(),
+                                     None if scratch is None else scratch[1].data_ptr(), out[0].data_ptr() if want_dbias else None,
+                                     out[1].data_ptr(), out[2].data_ptr(), _stream()), "slu_bn_act_bwd")
+    return da, (out[0] if want_dbias else None), (out[1] if has_bn else None), (out[2] if has_bn else None)
+
+
 def act_affine_bwd(dz, y=None, k1=None, k2=None, k3=None, slope=None, want_dbias=True):
     """da = (k1*dz + k2 + k3*y) * leaky'(y);  dbias f64[C] = sum da."""
     _req(dz, "dz")
