@@ -595,9 +595,16 @@ def train_step_block(dev, rank=0, world=1):
     except Exception as e:      # the extra block must never take the headline line down
         return {"error": f"{type(e).__name__}: {e}"}
     try:
-        return measure(dev, batch=4, steps=5, warmup=2, rank=rank, world=world)
+        res = measure(dev, batch=4, steps=5, warmup=2, rank=rank, world=world)
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"}
+    if world == 1:      # the same step replayed as ONE HIP graph, beside the eager number (GPU-bound step: the graph form is not faster here)
+        try:
+            g = measure(dev, batch=4, steps=5, warmup=2, graph=True)
+            res["hip_graph_variant"] = {"ms_per_step": g["ms_per_step"], "scans_per_s": g["value"]}
+        except Exception as e:
+            res["hip_graph_variant"] = {"error": f"{type(e).__name__}: {e}"}
+    return res
 
 
 def guarded_train_leg(dev, rank, world, timeout_s=240.0):
