@@ -3,6 +3,7 @@
 #pragma once
 #include <utility>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "slu_common.h"
 
@@ -263,6 +264,10 @@ inline long long wg_count(const ConvArgs& a, int th, int mblk) {
 // Tile choice: the biggest tile that still gives >= 2 workgroups per CU (256 CUs); below that,
 // shrink rows first (TH 8 -> 4), then the channel tile, so small feature maps still fill the chip.
 inline int choose_cfg(const ConvArgs& a) {
+  static const int forced = [] { const char* e = getenv("SLU_CONV_CFG"); return e ? atoi(e) : -1; }();      // development override: 0..4 = TileCfg
+  if (forced >= 0 && forced <= 4 && !(forced == M128_TH4 && a.nmblk < 4) && !((forced == M64_TH8 || forced == M64_TH4) && a.nmblk < 2) &&
+      !((forced == M32_TH8 || forced == M64_TH8) && a.H < 8))
+    return forced;
   const long long want = 512;
   if (a.nmblk >= 4) {
     if (wg_count(a, 4, 4) >= want) return M128_TH4;
@@ -274,7 +279,11 @@ inline int choose_cfg(const ConvArgs& a) {
     if (wg_count(a, 4, 2) >= want) return M64_TH4;
     return M32_TH4;
   }
-  if (a.H >= 8 && wg_count(a, 8, 1) >= want) return M32_TH8;
+  // 32 output channels: the 8-row tile runs 3 workgroups per CU (768 slots), the 4-row tile 4 (1 024 slots).  With only a round or two of tiles
+  // (a training batch of 4 scans at 64x2048 is 1 024 eight-row tiles = 1.33 rounds) the last, partly filled round costs more than the taller
+  // tile saves in halo: measured at B = 4 (tools/conv_layer_time.py, SLU_CONV_CFG): 32->32 3x3 134 -> 116 us, 64->32 3x3 217 -> 188, 96->32 1x1
+  // 76 -> 67.  Many rounds (inference batches): the taller tile.
+  if (a.H >= 8 && wg_count(a, 8, 1) >= 4 * 768) return M32_TH8;
   return M32_TH4;
 }
 
