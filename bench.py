@@ -512,6 +512,28 @@ def main(argv=None):
         lat = (time.perf_counter() - t1) / max(args.steps, 10)
         latency = {"latency_ms_per_scan": round(lat * 1e3, 3), "scans_per_s": round(1.0 / lat, 2),
                    "note": f"one scan per step (T = {Tt} stacked passes, every pass fully recomputed), same reduction and metric accumulation"}
+        if args.precision == "f16":      # the same stream with forward + head / MC reduction replayed as ONE HIP graph (graph_infer.py)
+            try:
+                from semanticlidarunc_amd.graph_infer import GraphedMCPredict
+                stream = GraphedMCPredict(model, x1, T=Tt)
+
+                def step1g():
+                    p_bar, h_norm, mi_norm, preds = stream(x1)
+                    iou.update(preds, l1)
+                    ece.update(p_bar, l1)
+
+                for _ in range(3):
+                    step1g()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(max(args.steps, 10)):
+                    step1g()
+                torch.cuda.synchronize()
+                latg = (time.perf_counter() - t1) / max(args.steps, 10)
+                latency["hip_graph_latency_ms_per_scan"] = round(latg * 1e3, 3)
+                del stream
+            except Exception as e:      # an extra: never takes the line down
+                latency["hip_graph_latency_ms_per_scan"] = f"error: {type(e).__name__}: {e}"
 
     # The Trainer's ECE configuration (trainer.py:215-222: max_samples = 500000 -> reservoir with host-drawn indices, one device sync per batch)
     # instead of the all-pixel bin accumulators of the headline loop: the same step, timed beside it

@@ -1410,13 +1410,19 @@ class DropoutPlan:
         self.outs = torch.from_numpy(ot.view(np.uint8).copy()).to(device)
         self.nsites, self.nout = len(sites), len(outs)
 
-    def run(self):
-        """{key: [n, C] multiplier}: one launch; consumes ceil(draws / 4) (rounded up to a multiple of 4) counters of torch's CUDA generator."""
+    def run(self, out: Optional[torch.Tensor] = None):
+        """{key: [n, C] multiplier}: one launch; consumes ceil(draws / 4) (rounded up to a multiple of 4) counters of torch's CUDA generator.
+        out: a float32 buffer of `self.total` elements to draw into (a captured HIP graph reads the multipliers from fixed addresses)."""
         gen = torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
         seed, off = int(gen.initial_seed()), int(gen.get_offset())
         adv = ((self.draws + 3) // 4 + 3) // 4 * 4
         gen.set_offset(off + adv)
-        buf = torch.empty(self.total, dtype=torch.float32, device=self.device)
+        if out is None:
+            buf = torch.empty(self.total, dtype=torch.float32, device=self.device)
+        else:
+            buf = _req(out, "out")
+            if buf.numel() != self.total:
+                raise RuntimeError(f"DropoutPlan.run: out holds {buf.numel()} elements, the plan needs {self.total}")
         check(_lib.load().slu_dropout_draw(self.sites.data_ptr(), self.nsites, self.outs.data_ptr(), self.nout, self.n, seed & (2 ** 64 - 1), off, buf.data_ptr(),
                                            self.total, _stream()), "slu_dropout_draw")
         return {key: buf[b:b + self.n * c].view(self.n, c) for key, b, c in self.slices}
