@@ -512,7 +512,7 @@ def main(argv=None):
         lat = (time.perf_counter() - t1) / max(args.steps, 10)
         latency = {"latency_ms_per_scan": round(lat * 1e3, 3), "scans_per_s": round(1.0 / lat, 2),
                    "note": f"one scan per step (T = {Tt} stacked passes, every pass fully recomputed), same reduction and metric accumulation"}
-        if args.precision == "f16":      # the same stream with forward + head / MC reduction replayed as ONE HIP graph (graph_infer.py)
+        if args.precision == "f16" and not os.environ.get("SLU_BENCH_NO_B1_GRAPH"):      # the same stream with forward + head / MC reduction replayed as ONE HIP graph (graph_infer.py)
             try:
                 from semanticlidarunc_amd.graph_infer import GraphedMCPredict
                 stream = GraphedMCPredict(model, x1, T=Tt)
